@@ -1,0 +1,138 @@
+"""CPU: the oracle restatement against the golden vectors generated from the
+imported reference (tests/golden/make_golden.py)."""
+import math
+
+import pytest
+import torch
+
+from conftest import load_json, BN_SHADOWED
+import oracle
+from oracle import steps
+
+
+def close(a, b, rel, abs_=0.0):
+    return abs(a - b) <= abs_ + rel * max(abs(a), abs(b))
+
+
+def test_state_dict_keys_match_reference_layout():
+    eg, d, _, _ = steps.build_nets()
+    g = load_json("step_b4.json")["fp32"]
+    assert list(eg.state_dict().keys()) == sorted(g["eg_state"].keys(), key=list(eg.state_dict().keys()).index)
+    assert set(eg.state_dict().keys()) == set(g["eg_state"].keys())
+    assert set(d.state_dict().keys()) == set(g["d_state"].keys())
+    n_eg = sum(p.numel() for p in eg.parameters())
+    n_d = sum(p.numel() for p in d.parameters())
+    assert (n_eg, n_d) == (73385795, 36122945)
+
+
+@pytest.mark.parametrize("tag,dtype,rel", [("fp32", torch.float32, 2e-5), ("fp64", torch.float64, 1e-10)])
+def test_kat0(tag, dtype, rel):
+    g = load_json("kat0.json")[tag]
+    eg, d, _, _ = steps.build_nets(dtype=dtype)
+    for k in ("features.0.weight", "x_to_mu.0.weight", "deconv1.weight"):
+        assert close(float(eg.state_dict()[k].double().sum()), g["w_sum/" + k], rel, 1e-5)
+    for k in ("convs.0.weight", "lth_features.0.weight"):
+        assert close(float(d.state_dict()[k].double().sum()), g["w_sum/D." + k], rel, 1e-5)
+    gen = torch.Generator().manual_seed(1234)
+    x = (torch.rand(4, 3, 64, 64, generator=gen) * 2 - 1).to(dtype)
+    eps = torch.randn(4, 128, generator=gen).to(dtype)
+    noise = torch.randn(4, 128, generator=gen).to(dtype)
+    assert close(float(x.double().sum()), g["x_sum"], 1e-6)
+    with torch.no_grad():
+        recon, mu, lv = eg(x, eps)
+        fake = eg.decode(noise)
+        p_real, f_real = d(x)
+        p_rec, f_rec = d(recon)
+        p_fake, _ = d(fake)
+    assert close(float(recon.double().sum()), g["recon"][0], rel * 10)
+    assert close(float(recon.double().abs().sum()), g["recon"][1], rel)
+    assert close(float(fake.double().abs().sum()), g["fake"][1], rel)
+    assert close(float(mu.double().abs().sum()), g["mu"][1], rel)
+    for a, b in zip(p_real.tolist() + p_rec.tolist() + p_fake.tolist(), g["p_real"] + g["p_rec"] + g["p_fake"]):
+        assert close(a, b, rel * 5)
+    assert close(float(steps.kld_loss(mu, lv, 1.0)), g["kl_beta1"], rel * 5)
+    assert close(float(steps.recon_loss(recon, x)), g["mse"], rel)
+    assert close(float(steps.sim_loss(f_rec, f_real)), g["dis_l"], rel * 5)
+    assert close(float(steps.bce_loss(p_real, 0.9)), g["bce_real_0.9"], rel * 5)
+    assert close(float(steps.bce_loss(p_fake, 0.1)), g["bce_fake_0.1"], rel * 5)
+    assert int(eg.state_dict()["features.1.num_batches_tracked"]) == g["bn_nbt"]
+
+
+def _check_state(state, gold, skip, rel, abs_):
+    for k, v in state.items():
+        if k in skip:
+            continue
+        s, a = float(v.double().sum()), float(v.double().abs().sum())
+        assert close(a, gold[k][1], rel, abs_), (k, a, gold[k][1])
+        assert close(s, gold[k][0], rel, abs_ + rel * a), (k, s, gold[k][0])
+
+
+@pytest.mark.parametrize("batch", [4, 16])
+def test_betavaegan_step_fp32(batch):
+    g = load_json(f"step_b{batch}.json")["fp32"]
+    eg, d, oeg, od = steps.build_nets()
+    b = steps.synthetic_batch(batch)
+    grads = {}
+    losses = steps.betavaegan_step(eg, d, oeg, od, b["data"], b["noise"], b["eps2"], b["eps3"], beta=25.0,
+                                   grad_hook=lambda ph, net: grads.__setitem__(
+                                       ph, {k: float(p.grad.double().norm()) for k, p in net.named_parameters()}))
+    for k, v in g["losses"].items():
+        assert close(losses[k], v, 1e-4), (k, losses[k], v)
+    for ph, key in (("D", "d"), ("EG2", "eg"), ("EG3", "eg")):
+        for k, v in g["grad_norms"][ph].items():
+            if k in BN_SHADOWED[key]:
+                continue
+            assert close(grads[ph][k], v, 1e-3, 1e-6), (ph, k, grads[ph][k], v)
+    # one Adam step moves every weight by ~lr; checksums of |w| move by <= lr*numel
+    _check_state(eg.state_dict(), g["eg_state"], BN_SHADOWED["eg"], 1e-4, 1e-4)
+    _check_state(d.state_dict(), g["d_state"], BN_SHADOWED["d"], 1e-4, 1e-4)
+    assert int(d.state_dict()["convs.1.num_batches_tracked"]) == 5
+    assert int(eg.state_dict()["features.1.num_batches_tracked"]) == 2
+    assert int(eg.state_dict()["act1.0.num_batches_tracked"]) == 3
+
+
+def test_betavaegan_step_fp64_b4():
+    g = load_json("step_b4.json")["fp64"]
+    eg, d, oeg, od = steps.build_nets(dtype=torch.float64)
+    b = steps.synthetic_batch(4, dtype=torch.float64)
+    losses = steps.betavaegan_step(eg, d, oeg, od, b["data"], b["noise"], b["eps2"], b["eps3"], beta=25.0)
+    for k, v in g["losses"].items():
+        assert close(losses[k], v, 1e-9), (k, losses[k], v)
+
+
+def test_vae_step_b16():
+    g = load_json("vae_step_b16.json")["fp32"]
+    torch.manual_seed(999)
+    m = oracle.VAE(oracle.OracleOpt())
+    m.apply(oracle.weights_init)
+    o = torch.optim.Adam(m.parameters(), lr=3e-3)
+    b = steps.synthetic_batch(16)
+    losses = steps.vae_step(m, o, b["data"], b["eps2"], beta=1.0)
+    for k, v in g["losses"].items():
+        assert close(losses[k], v, 1e-4)
+    _check_state(m.state_dict(), g["state"], BN_SHADOWED["eg"], 1e-4, 1e-4)
+
+
+def test_gan_step_b4():
+    g = load_json("gan_step_b4.json")["fp32"]
+    torch.manual_seed(999)
+    gen = oracle.Generator_celeba(oracle.OracleOpt())
+    d = oracle.Discriminator_celeba(oracle.OracleOpt())
+    gen.apply(oracle.weights_init)
+    d.apply(oracle.weights_init)
+    og = torch.optim.Adam(gen.parameters(), lr=3e-3)
+    od = torch.optim.Adam(d.parameters(), lr=3e-3)
+    b = steps.synthetic_batch(4)
+    losses = steps.gan_step(gen, d, og, od, b["data"], b["noise"])
+    for k, v in g["losses"].items():
+        assert close(losses[k], v, 1e-4)
+    _check_state(gen.state_dict(), g["g_state"], BN_SHADOWED["g"], 1e-4, 1e-4)
+    _check_state(d.state_dict(), g["d_state"], BN_SHADOWED["d"], 1e-4, 1e-4)
+
+
+def test_encoder_celeba_returns_per_sample_kld():
+    torch.manual_seed(1)
+    e = oracle.Encoder_celeba(oracle.OracleOpt())
+    z, kld = e(torch.randn(3, 3, 64, 64), eps=torch.zeros(3, 128))
+    assert z.shape == (3, 128) and kld.shape == (3,)
+    assert all(math.isfinite(v) for v in kld.tolist())
