@@ -1,0 +1,64 @@
+"""ctypes binding of libvaegan_hip.so (include/vaegan_hip.h).
+
+The library is the product's only compute path for the convolutions, BatchNorm,
+activations and losses.  There is NO CPU or PyTorch fallback: if the shared
+object is missing or a symbol is absent, import fails loudly.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvaegan_hip.so")
+
+_P, _I, _F, _Z = c_void_p, c_int, c_float, c_size_t
+
+# name -> (restype, argtypes); mirrors include/vaegan_hip.h one to one
+SIGNATURES = {
+    "vg_version": (_I, []),
+    "vg_conv5x5_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vg_convT5x5_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vg_conv5x5_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "vg_conv5x5_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "vg_channel_sum": (_I, [_P, _P, _I, _I, _I, _P, _Z, _P]),
+    "vg_bn_workspace_bytes": (_Z, [_I]),
+    "vg_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P, _Z, _P]),
+    "vg_bn_act_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
+    "vg_bias_act_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "vg_act_bwd": (_I, [_P, _P, _P, _Z, _I, _P]),
+    "vg_reparam_kl_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "vg_reparam_kl_bwd": (_I, [_P, _P, _P, _P, _F, _F, _P, _P, _I, _I, _P]),
+    "vg_sqdiff_workspace_bytes": (_Z, [_Z]),
+    "vg_sqdiff_loss": (_I, [_P, _P, _P, _P, _Z, _F, _F, _P, _Z, _P]),
+    "vg_bce_loss": (_I, [_P, _F, _P, _P, _I, _F, _F, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -m disentangle_mlp_amd.build` "
+            "(hipcc --offload-arch=gfx950). disentangle_mlp_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+def check(status, name):
+    if status != 0:
+        what = {-1: "bad argument", -2: "workspace too small"}.get(status, f"hipError_t {status}")
+        raise HipKernelError(f"{name} failed: {what}")

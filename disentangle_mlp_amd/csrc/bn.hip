@@ -1,0 +1,365 @@
+// Train-mode BatchNorm (2-D and 1-D) fused with ReLU / LeakyReLU(0.2), forward and
+// backward, plus the per-channel sum used for convolution bias gradients.
+// HBM-bound kernels: float4 coalesced streams over NCHW planes, fp64 partial sums
+// reduced with 64-lane wavefront shuffles, deterministic two-stage reductions.
+//
+// Replaces F.batch_norm(training=True) + activation reached from
+// /root/reference/models/model.py:451-458 (encoder), :462,468 (heads), :492
+// (decoder preprocess), :496-505 (decoder), :390-400 (discriminator).
+#include "common.hpp"
+#include "vaegan_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int NS_MAX = 64;   // slices per channel in the two-stage reductions
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+  if (act == VG_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == VG_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
+  return v;
+}
+__device__ __forceinline__ float act_grad(float pre, float g, int act) {
+  if (act == VG_ACT_RELU) return pre > 0.f ? g : 0.f;
+  if (act == VG_ACT_LRELU) return pre > 0.f ? g : 0.2f * g;
+  return g;
+}
+
+struct Slicing {
+  int ns;        // slices per channel
+  long per;      // virtual elements (b*HW+hw) per slice, multiple of 4 when HW%4==0
+};
+Slicing make_slicing(int B, int C, int HW) {
+  const long total = (long)B * HW;
+  long ns = 2048 / C;
+  if (ns < 1) ns = 1;
+  if (ns > NS_MAX) ns = NS_MAX;
+  long per = (total + ns - 1) / ns;
+  if (per < 1024) per = 1024;
+  per = (per + 3) / 4 * 4;
+  ns = (total + per - 1) / per;
+  Slicing s;
+  s.ns = (int)ns;
+  s.per = per;
+  return s;
+}
+
+// MODE 0: sum x, sum x^2.   MODE 1: sum g_pre, sum g_pre*xhat (backward).   MODE 2: sum x only.
+template <int MODE>
+__global__ __launch_bounds__(NT) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, double* __restrict__ part,
+                                                        int B, int C, int HW, long per, int ns, int act) {
+  __shared__ double red[NT / 64];
+  const int c = blockIdx.x, k = blockIdx.y;
+  const long total = (long)B * HW;
+  const long v0 = (long)k * per, v1 = min(v0 + per, total);
+  double s1 = 0.0, s2 = 0.0;
+  float mu = 0.f, is = 0.f, sc = 0.f, sh = 0.f;
+  if (MODE == 1) {
+    mu = mean[c];
+    is = invstd[c];
+    sc = gamma[c] * is;
+    sh = beta[c] - mu * sc;
+  }
+  auto accum = [&](float xv, float gv) {
+    if (MODE == 0) {
+      s1 += xv;
+      s2 += (double)xv * xv;
+    } else if (MODE == 2) {
+      s1 += xv;
+    } else {
+      const float g = act_grad(fmaf(xv, sc, sh), gv, act);
+      s1 += g;
+      s2 += (double)(g * ((xv - mu) * is));
+    }
+  };
+  if ((HW & 3) == 0) {
+    for (long v = v0 + 4L * threadIdx.x; v < v1; v += 4L * NT) {
+      const long b = v / HW, hw = v - b * HW;
+      const size_t off = ((size_t)b * C + c) * HW + hw;
+      const float4 xv = *reinterpret_cast<const float4*>(x + off);
+      float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (MODE == 1) gv = *reinterpret_cast<const float4*>(gy + off);
+      accum(xv.x, gv.x);
+      accum(xv.y, gv.y);
+      accum(xv.z, gv.z);
+      accum(xv.w, gv.w);
+    }
+  } else {
+    for (long v = v0 + threadIdx.x; v < v1; v += NT) {
+      const long b = v / HW, hw = v - b * HW;
+      const size_t off = ((size_t)b * C + c) * HW + hw;
+      accum(x[off], MODE == 1 ? gy[off] : 0.f);
+    }
+  }
+  const double t1 = block_sum<NT>(s1, red);
+  const double t2 = block_sum<NT>(s2, red);
+  if (threadIdx.x == 0) {
+    part[((size_t)c * ns + k) * 2 + 0] = t1;
+    part[((size_t)c * ns + k) * 2 + 1] = t2;
+  }
+}
+
+__global__ __launch_bounds__(NT) void bn_fwd_finalize_kernel(const double* __restrict__ part, int ns, int C,
+                                                             double count, float eps, float momentum,
+                                                             float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var,
+                                                             float* __restrict__ save_mean,
+                                                             float* __restrict__ save_invstd,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             float4* __restrict__ cf) {
+  const int c = blockIdx.x * NT + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < ns; ++k) {
+    s1 += part[((size_t)c * ns + k) * 2];
+    s2 += part[((size_t)c * ns + k) * 2 + 1];
+  }
+  const double m = s1 / count;
+  double var = s2 / count - m * m;
+  if (var < 0.0) var = 0.0;
+  const float mu = (float)m, is = (float)(1.0 / sqrt(var + (double)eps));
+  save_mean[c] = mu;
+  save_invstd[c] = is;
+  const float sc = gamma[c] * is;
+  cf[c] = make_float4(sc, beta[c] - mu * sc, mu, is);
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+  if (running_var) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+__global__ __launch_bounds__(NT) void bn_bwd_finalize_kernel(const double* __restrict__ part, int ns, int C,
+                                                             double count, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             float4* __restrict__ cf, float2* __restrict__ cb) {
+  const int c = blockIdx.x * NT + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < ns; ++k) {
+    s1 += part[((size_t)c * ns + k) * 2];
+    s2 += part[((size_t)c * ns + k) * 2 + 1];
+  }
+  if (dbeta) dbeta[c] = (float)s1;
+  if (dgamma) dgamma[c] = (float)s2;
+  const float mu = mean[c], is = invstd[c], sc = gamma[c] * is;
+  cf[c] = make_float4(sc, beta[c] - mu * sc, mu, is);
+  cb[c] = make_float2((float)(s1 / count), (float)(s2 / count));
+}
+
+__global__ __launch_bounds__(NT) void channel_sum_finalize_kernel(const double* __restrict__ part, int ns, int C,
+                                                                  float* __restrict__ out) {
+  const int c = blockIdx.x * NT + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0;
+  for (int k = 0; k < ns; ++k) s1 += part[((size_t)c * ns + k) * 2];
+  out[c] = (float)s1;
+}
+
+// Flat float4 stream over [B][C][HW]; per-channel coefficients come from the small
+// cf/cb tables written by the finalize kernels (L1/L2 resident).
+// FWD: y = act(x*sc + sh).   BWD: gx = sc * (g_pre - c1 - xhat*c2).
+template <bool BWD>
+__global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                      const float4* __restrict__ cf,
+                                                      const float2* __restrict__ cb, float* __restrict__ out,
+                                                      int C, int HW, size_t n, int act) {
+  auto one = [&](float xv, float gv, const float4& f, const float2& bw) -> float {
+    const float pre = fmaf(xv, f.x, f.y);
+    if (!BWD) return act_fwd(pre, act);
+    const float g = act_grad(pre, gv, act);
+    return f.x * (g - bw.x - ((xv - f.z) * f.w) * bw.y);
+  };
+  const size_t stride = (size_t)gridDim.x * NT;
+  if ((HW & 3) == 0) {
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += stride) {
+      const int c = (int)(((i << 2) / HW) % C);
+      const float4 f = cf[c];
+      float2 bw = make_float2(0.f, 0.f);
+      if (BWD) bw = cb[c];
+      const float4 xv = reinterpret_cast<const float4*>(x)[i];
+      float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (BWD) gv = reinterpret_cast<const float4*>(gy)[i];
+      float4 o;
+      o.x = one(xv.x, gv.x, f, bw);
+      o.y = one(xv.y, gv.y, f, bw);
+      o.z = one(xv.z, gv.z, f, bw);
+      o.w = one(xv.w, gv.w, f, bw);
+      reinterpret_cast<float4*>(out)[i] = o;
+    }
+  } else {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) {
+      const int c = (int)((i / HW) % C);
+      const float4 f = cf[c];
+      float2 bw = make_float2(0.f, 0.f);
+      if (BWD) bw = cb[c];
+      out[i] = one(x[i], BWD ? gy[i] : 0.f, f, bw);
+    }
+  }
+}
+
+// BatchNorm1d: x [B][C]; one thread per channel, lanes sweep consecutive channels
+// (coalesced); the second pass over the B rows is served from L2.
+__global__ __launch_bounds__(NT) void bn1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ y,
+                                                      float* __restrict__ running_mean,
+                                                      float* __restrict__ running_var, float* __restrict__ save_mean,
+                                                      float* __restrict__ save_invstd, int B, int C, float eps,
+                                                      float momentum, int act) {
+  const int c = blockIdx.x * NT + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const float v = x[(size_t)b * C + c];
+    s1 += v;
+    s2 += (double)v * v;
+  }
+  const double m = s1 / B;
+  double var = s2 / B - m * m;
+  if (var < 0.0) var = 0.0;
+  const float mu = (float)m, is = (float)(1.0 / sqrt(var + (double)eps));
+  save_mean[c] = mu;
+  save_invstd[c] = is;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+  if (running_var) {
+    const double unb = B > 1 ? var * B / (B - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+  const float sc = gamma[c] * is, sh = beta[c] - mu * sc;
+  for (int b = 0; b < B; ++b) {
+    const size_t o = (size_t)b * C + c;
+    y[o] = act_fwd(fmaf(x[o], sc, sh), act);
+  }
+}
+
+__global__ __launch_bounds__(NT) void bn1d_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta,
+                                                      const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd, float* __restrict__ gx,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int B,
+                                                      int C, int act) {
+  const int c = blockIdx.x * NT + threadIdx.x;
+  if (c >= C) return;
+  const float mu = mean[c], is = invstd[c];
+  const float sc = gamma[c] * is, sh = beta[c] - mu * sc;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const size_t o = (size_t)b * C + c;
+    const float xv = x[o];
+    const float g = act_grad(fmaf(xv, sc, sh), gy[o], act);
+    s1 += g;
+    s2 += (double)(g * ((xv - mu) * is));
+  }
+  if (dbeta) dbeta[c] = (float)s1;
+  if (dgamma) dgamma[c] = (float)s2;
+  const float c1 = (float)(s1 / B), c2 = (float)(s2 / B);
+  for (int b = 0; b < B; ++b) {
+    const size_t o = (size_t)b * C + c;
+    const float xv = x[o];
+    const float g = act_grad(fmaf(xv, sc, sh), gy[o], act);
+    gx[o] = sc * (g - c1 - ((xv - mu) * is) * c2);
+  }
+}
+
+size_t part_bytes(int C) { return (size_t)C * NS_MAX * 2 * sizeof(double); }
+size_t ws_bytes(int C) { return part_bytes(C) + (size_t)C * (sizeof(float4) + sizeof(float2)) + 64; }
+int apply_grid(size_t n) {
+  const size_t blocks = (n / 4 + NT - 1) / NT;
+  return (int)(blocks > 4096 ? 4096 : (blocks < 1 ? 1 : blocks));
+}
+
+}  // namespace
+
+extern "C" size_t vg_bn_workspace_bytes(int C) { return C > 0 ? ws_bytes(C) : 0; }
+
+extern "C" int vg_bn_act_fwd(const float* x, const float* gamma, const float* beta, float* y, float* running_mean,
+                             float* running_var, float* save_mean, float* save_invstd, int B, int C, int HW,
+                             float eps, float momentum, int act, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || B <= 0 || C <= 0 || HW <= 0)
+    return VG_ERR_BAD_ARG;
+  if (act < VG_ACT_NONE || act > VG_ACT_LRELU) return VG_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (HW == 1) {
+    hipLaunchKernelGGL(bn1d_fwd_kernel, dim3(cdiv(C, NT)), dim3(NT), 0, st, x, gamma, beta, y, running_mean,
+                       running_var, save_mean, save_invstd, B, C, eps, momentum, act);
+    VG_CHECK_LAUNCH();
+    return 0;
+  }
+  if (!workspace || workspace_bytes < ws_bytes(C)) return VG_ERR_WORKSPACE;
+  double* part = (double*)workspace;
+  const Slicing s = make_slicing(B, C, HW);
+  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(C, s.ns), dim3(NT), 0, st, x, (const float*)nullptr, gamma, beta,
+                     (const float*)nullptr, (const float*)nullptr, part, B, C, HW, s.per, s.ns, act);
+  VG_CHECK_LAUNCH();
+  float4* cf = (float4*)((char*)workspace + part_bytes(C));
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(C, NT)), dim3(NT), 0, st, (const double*)part, s.ns, C,
+                     (double)B * HW, eps, momentum, running_mean, running_var, save_mean, save_invstd, gamma, beta,
+                     cf);
+  VG_CHECK_LAUNCH();
+  const size_t n = (size_t)B * C * HW;
+  hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(apply_grid(n)), dim3(NT), 0, st, x, (const float*)nullptr,
+                     (const float4*)cf, (const float2*)nullptr, y, C, HW, n, act);
+  VG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vg_bn_act_bwd(const float* gy, const float* x, const float* gamma, const float* beta,
+                             const float* save_mean, const float* save_invstd, float* gx, float* dgamma,
+                             float* dbeta, int B, int C, int HW, int act, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  if (!gy || !x || !gamma || !beta || !save_mean || !save_invstd || !gx || B <= 0 || C <= 0 || HW <= 0)
+    return VG_ERR_BAD_ARG;
+  if (act < VG_ACT_NONE || act > VG_ACT_LRELU) return VG_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (HW == 1) {
+    hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(cdiv(C, NT)), dim3(NT), 0, st, gy, x, gamma, beta, save_mean,
+                       save_invstd, gx, dgamma, dbeta, B, C, act);
+    VG_CHECK_LAUNCH();
+    return 0;
+  }
+  if (!workspace || workspace_bytes < ws_bytes(C)) return VG_ERR_WORKSPACE;
+  double* part = (double*)workspace;
+  float4* cf = (float4*)((char*)workspace + part_bytes(C));
+  float2* cb = (float2*)(cf + C);
+  const Slicing s = make_slicing(B, C, HW);
+  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(C, s.ns), dim3(NT), 0, st, x, gy, gamma, beta, save_mean,
+                     save_invstd, part, B, C, HW, s.per, s.ns, act);
+  VG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, NT)), dim3(NT), 0, st, (const double*)part, s.ns, C,
+                     (double)B * HW, dgamma, dbeta, gamma, beta, save_mean, save_invstd, cf, cb);
+  VG_CHECK_LAUNCH();
+  const size_t n = (size_t)B * C * HW;
+  hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(apply_grid(n)), dim3(NT), 0, st, x, gy, (const float4*)cf,
+                     (const float2*)cb, gx, C, HW, n, act);
+  VG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vg_channel_sum(const float* g, float* out, int B, int C, int HW, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  if (!g || !out || B <= 0 || C <= 0 || HW <= 0) return VG_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < ws_bytes(C)) return VG_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  double* part = (double*)workspace;
+  const Slicing s = make_slicing(B, C, HW);
+  hipLaunchKernelGGL(bn_partial_kernel<2>, dim3(C, s.ns), dim3(NT), 0, st, g, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                     part, B, C, HW, s.per, s.ns, 0);
+  VG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(cdiv(C, NT)), dim3(NT), 0, st, (const double*)part, s.ns,
+                     C, out);
+  VG_CHECK_LAUNCH();
+  return 0;
+}

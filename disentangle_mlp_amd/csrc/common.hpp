@@ -1,0 +1,61 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) beta-VAE-GAN kernels.
+// 64-wide wavefronts, fp32-input MFMA (v_mfma_f32_32x32x2_f32: exact fp32,
+// bitwise a k-ordered fmaf chain), LDS-staged NCHW patches.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define VG_WAVE 64
+
+#define VG_CHECK_LAUNCH()                         \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) return (int)e__;       \
+  } while (0)
+
+// D(32x32) += A(32x2) * B(2x32).  Lane l supplies A[i=l&31][k=l>>5] and
+// B[k=l>>5][j=l&31]; D register r of lane l is D[i=(r&3)+8*(r>>2)+4*(l>>5)][j=l&31].
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int acc_row(int r, int lane) {
+  return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+
+// ---- wavefront / block reductions (64 lanes; no 32-lane idioms) -------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;  // valid in lane 0
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_allsum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Sum over a block of NT threads (NT multiple of 64); result valid in thread 0.
+// `red` is LDS scratch of at least NT/64 elements.
+template <int NT, typename T>
+__device__ __forceinline__ T block_sum(T v, T* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  T t = 0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) t += red[i];
+  }
+  return t;
+}
+
+__host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,267 @@
+// Weight gradient of the 5x5 / pad 2 / stride {1,2} convolutions (and, with the
+// operand roles swapped, of the transposed convolutions) for gfx950: an implicit
+// GEMM on the fp32-input MFMA with the reduction over (image, output pixel).
+//
+//   dw[co][ci][kh][kw] = sum_{b,oh,ow} gy[b][co][oh][ow] * x[b][ci][S*oh+kh-2][S*ow+kw-2]
+//
+// Autograd of nn.Conv2d / nn.ConvTranspose2d at /root/reference/models/model.py:
+// 389-398, 450-456, 495-507, reached from the backward() calls of
+// experiments/new_betavaegan.py:103,121,157-163,185-187.
+//
+// GEMM view: D[co][n], n = ci*25 + tap, K = (b, oh, ow).  A workgroup owns TM
+// output channels x 5 input channels (125 of 128 MFMA columns) and a slice of
+// K (split-K over images / pixel tiles).  Per K chunk (one image, 64 output
+// pixels) it stages gy[TM][64] (contiguous NCHW rows) and the input patch
+// [5][PH][PW] in LDS; lane (j,h) reads x-patch[ci(j)][S*oh+kh(j)][S*ow+kw(j)] at a
+// per-lane base + compile-time immediate.  Partial slabs go to the workspace
+// and are summed in a fixed order by a second kernel (deterministic, no atomics).
+#include "common.hpp"
+#include "vaegan_hip.h"
+
+namespace {
+
+constexpr int WG_NT = 256;
+constexpr int CIT = 5;    // input channels per column tile (125 of 128 columns used)
+constexpr int KC = 64;    // output pixels per K chunk
+
+template <int S_, int TW_, int TM_>
+struct WCfg {
+  static constexpr int S = S_, TW = TW_, TH = KC / TW_, TM = TM_;
+  static constexpr int WM = (TM >= 64) ? 2 : 1, WN = 4 / WM;
+  static constexpr int FC = TM / 32 / WM, FN = 128 / 32 / WN;
+  static constexpr int PH = S * (TH - 1) + 5, PW = S * (TW - 1) + 5, PWP = PW | 1;
+  static constexpr int NPATCH = CIT * PH * PWP;
+  static constexpr int AS = KC + 1;
+  static constexpr int STAGE = TM * AS + NPATCH;
+  static constexpr int NQP = cdiv(NPATCH, WG_NT), NQA = TM / 4;
+};
+
+struct WArgs {
+  const float* x;
+  const float* gy;
+  float* ws;
+  int B, Cin, H, W, Cout, OH, OW;
+  int mtiles, ntiles, splits, tiles_w, tiles_hw, chunks, chunks_per_split;
+};
+
+template <class C>
+__global__ __launch_bounds__(WG_NT, 2) void conv5x5_wgrad_kernel(WArgs A) {
+  constexpr int S = C::S, TW = C::TW, TH = C::TH, TM = C::TM, FC = C::FC, FN = C::FN;
+  constexpr int PH = C::PH, PW = C::PW, PWP = C::PWP, NPATCH = C::NPATCH, AS = C::AS;
+  constexpr int NQP = C::NQP, NQA = C::NQA;
+  __shared__ float smem[C::STAGE];
+  float* gyl = smem;
+  float* pl = smem + TM * AS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int h = lane >> 5, l32 = lane & 31;
+  const int wm = wid % C::WM, wn = wid / C::WM;
+  int bid = blockIdx.x;
+  const int mt = bid % A.mtiles;
+  bid /= A.mtiles;
+  const int nt = bid % A.ntiles, split = bid / A.ntiles;
+  const int m0 = mt * TM, ci0 = nt * CIT;
+  const int Cin = A.Cin, Cout = A.Cout, H = A.H, W = A.W, OH = A.OH, OW = A.OW;
+  const int HW = H * W, OHW = OH * OW;
+
+  // ---- staging maps
+  int pk[NQP], prc[NQP];
+#pragma unroll
+  for (int q = 0; q < NQP; ++q) {
+    const int e = tid + q * WG_NT;
+    const int col = e % PWP;
+    int t = e / PWP;
+    const int r = t % PH, ci_l = t / PH;
+    const bool ok = e < NPATCH && col < PW && (ci0 + ci_l) < Cin;
+    pk[q] = ok ? ci_l * HW + r * W + col : -1;
+    prc[q] = r | (col << 16);
+  }
+  const int a_pix = lane;  // this thread's pixel within the chunk tile
+  const int a_ph = a_pix / TW, a_pw = a_pix % TW;
+
+  float preg[NQP], areg[NQA];
+  auto load_chunk = [&](int chunk) {
+    const int b = chunk / A.tiles_hw, sp = chunk % A.tiles_hw;
+    const int th0 = (sp / A.tiles_w) * TH, tw0 = (sp % A.tiles_w) * TW;
+    const int ih0 = S * th0 - 2, iw0 = S * tw0 - 2;
+    const float* xb = A.x + ((size_t)b * Cin + ci0) * HW;
+    const int shift = ih0 * W + iw0;
+#pragma unroll
+    for (int q = 0; q < NQP; ++q) {
+      const int ih = ih0 + (prc[q] & 0xffff), iw = iw0 + (prc[q] >> 16);
+      const bool ok = pk[q] >= 0 && ih >= 0 && ih < H && iw >= 0 && iw < W;
+      preg[q] = ok ? xb[pk[q] + shift] : 0.f;
+    }
+    const int oh = th0 + a_ph, ow = tw0 + a_pw;
+    const bool pok = oh < OH && ow < OW;
+    const float* gb = A.gy + ((size_t)b * Cout + m0 + wid) * OHW + oh * OW + ow;
+#pragma unroll
+    for (int q = 0; q < NQA; ++q) {
+      const bool ok = pok && (m0 + wid + 4 * q) < Cout;
+      areg[q] = ok ? gb[(size_t)q * 4 * OHW] : 0.f;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int q = 0; q < NQP; ++q) {
+      const int e = tid + q * WG_NT;
+      if (e < NPATCH) pl[e] = preg[q];
+    }
+#pragma unroll
+    for (int q = 0; q < NQA; ++q) gyl[(wid + 4 * q) * AS + a_pix] = areg[q];
+  };
+
+  // ---- per-lane operand bases
+  int base_a[FC], base_b[FN];
+#pragma unroll
+  for (int g = 0; g < FC; ++g) base_a[g] = ((wm * FC + g) * 32 + l32) * AS + h;
+#pragma unroll
+  for (int f = 0; f < FN; ++f) {
+    const int n = (wn * FN + f) * 32 + l32;
+    const int ci_l = n / 25, tap = n % 25;
+    base_b[f] = (n < CIT * 25) ? TM * AS + (ci_l * PH + tap / 5) * PWP + tap % 5 + h * S : TM * AS;
+  }
+
+  f32x16 acc[FC][FN];
+#pragma unroll
+  for (int g = 0; g < FC; ++g)
+#pragma unroll
+    for (int f = 0; f < FN; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[g][f][r] = 0.f;
+
+  const int c_begin = split * A.chunks_per_split;
+  const int c_end = min(c_begin + A.chunks_per_split, A.chunks);
+  if (c_begin < c_end) {
+    load_chunk(c_begin);
+    store_chunk();
+    __syncthreads();
+    for (int ch = c_begin; ch < c_end; ++ch) {
+      const bool more = (ch + 1) < c_end;
+      if (more) load_chunk(ch + 1);
+#pragma unroll
+      for (int kp = 0; kp < KC / 2; ++kp) {
+        const int k = 2 * kp;
+        const int imm_b = (S * (k / TW)) * PWP + S * (k % TW);
+        float a[FC], b[FN];
+#pragma unroll
+        for (int g = 0; g < FC; ++g) a[g] = smem[base_a[g] + k];
+#pragma unroll
+        for (int f = 0; f < FN; ++f) b[f] = smem[base_b[f] + imm_b];
+#pragma unroll
+        for (int g = 0; g < FC; ++g)
+#pragma unroll
+          for (int f = 0; f < FN; ++f) acc[g][f] = mfma32(a[g], b[f], acc[g][f]);
+      }
+      __syncthreads();
+      if (more) {
+        store_chunk();
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- partial slab store: ws[split][co][ci*25+tap] (lanes = consecutive n: coalesced)
+  float* wsb = A.ws + (size_t)split * Cout * Cin * 25;
+#pragma unroll
+  for (int f = 0; f < FN; ++f) {
+    const int n = (wn * FN + f) * 32 + l32;
+    const bool nok = n < CIT * 25 && (ci0 + n / 25) < Cin;
+#pragma unroll
+    for (int g = 0; g < FC; ++g) {
+#pragma unroll
+      for (int r16 = 0; r16 < 16; ++r16) {
+        const int co = m0 + (wm * FC + g) * 32 + acc_row(r16, lane);
+        if (nok && co < Cout) wsb[((size_t)co * Cin + ci0) * 25 + n] = acc[g][f][r16];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                           int n, int splits) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += ws[(size_t)k * n + i];
+  dw[i] = s;
+}
+
+struct Plan {
+  int tw, tm, mtiles, ntiles, splits, tiles_w, tiles_hw, chunks, cps, OH, OW;
+};
+
+Plan make_plan(int B, int Cin, int H, int W, int Cout, int S) {
+  Plan p;
+  p.OH = (H - 1) / S + 1;
+  p.OW = (W - 1) / S + 1;
+  p.tw = p.OW <= 8 ? 8 : (p.OW <= 16 ? 16 : (p.OW <= 32 ? 32 : 64));
+  p.tm = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
+  p.mtiles = cdiv(Cout, p.tm);
+  p.ntiles = cdiv(Cin, CIT);
+  const int th = KC / p.tw;
+  p.tiles_w = cdiv(p.OW, p.tw);
+  p.tiles_hw = p.tiles_w * cdiv(p.OH, th);
+  p.chunks = B * p.tiles_hw;
+  int want = cdiv(1024, p.mtiles * p.ntiles);
+  if (want > p.chunks) want = p.chunks;
+  if (want < 1) want = 1;
+  p.cps = cdiv(p.chunks, want);
+  p.splits = cdiv(p.chunks, p.cps);
+  return p;
+}
+
+template <class C>
+int launch_w(const WArgs& A, hipStream_t st) {
+  const long grid = (long)A.mtiles * A.ntiles * A.splits;
+  hipLaunchKernelGGL(conv5x5_wgrad_kernel<C>, dim3((unsigned)grid), dim3(WG_NT), 0, st, A);
+  VG_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int S, int TW>
+int dispatch_tm(const WArgs& A, int tm, hipStream_t st) {
+  if (tm == 128) return launch_w<WCfg<S, TW, 128>>(A, st);
+  if (tm == 64) return launch_w<WCfg<S, TW, 64>>(A, st);
+  return launch_w<WCfg<S, TW, 32>>(A, st);
+}
+
+template <int S>
+int dispatch_tw(const WArgs& A, int tw, int tm, hipStream_t st) {
+  switch (tw) {
+    case 8: return dispatch_tm<S, 8>(A, tm, st);
+    case 16: return dispatch_tm<S, 16>(A, tm, st);
+    case 32: return dispatch_tm<S, 32>(A, tm, st);
+    default: return dispatch_tm<S, 64>(A, tm, st);
+  }
+}
+
+}  // namespace
+
+extern "C" size_t vg_conv5x5_wgrad_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return 0;
+  const Plan p = make_plan(B, Cin, H, W, Cout, stride);
+  return (size_t)p.splits * Cout * Cin * 25 * sizeof(float);
+}
+
+extern "C" int vg_conv5x5_wgrad(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W,
+                                int Cout, int stride, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !gy || !dw || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return VG_ERR_BAD_ARG;
+  if (stride != 1 && stride != 2) return VG_ERR_BAD_ARG;
+  const Plan p = make_plan(B, Cin, H, W, Cout, stride);
+  const size_t need = (size_t)p.splits * Cout * Cin * 25 * sizeof(float);
+  if (!workspace || workspace_bytes < need) return VG_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  WArgs A;
+  A.x = x; A.gy = gy; A.ws = (float*)workspace;
+  A.B = B; A.Cin = Cin; A.H = H; A.W = W; A.Cout = Cout; A.OH = p.OH; A.OW = p.OW;
+  A.mtiles = p.mtiles; A.ntiles = p.ntiles; A.splits = p.splits;
+  A.tiles_w = p.tiles_w; A.tiles_hw = p.tiles_hw; A.chunks = p.chunks; A.chunks_per_split = p.cps;
+  int rc = (stride == 2) ? dispatch_tw<2>(A, p.tw, p.tm, st) : dispatch_tw<1>(A, p.tw, p.tm, st);
+  if (rc) return rc;
+  const int n = Cout * Cin * 25;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)workspace, dw, n,
+                     p.splits);
+  VG_CHECK_LAUNCH();
+  return 0;
+}

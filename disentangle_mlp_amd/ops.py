@@ -1,0 +1,209 @@
+"""Tensor-level wrappers over the C-ABI HIP library (include/vaegan_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every
+arithmetic op below runs in libvaegan_hip.so.  Inputs must be CUDA (ROCm) fp32
+tensors -- there is deliberately no CPU path.
+"""
+import torch
+
+from . import _lib
+from ._lib import check
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+EW_LRELU, EW_TANH, EW_SIGMOID = 0, 1, 2
+
+_workspaces = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: disentangle_mlp_amd ops need CUDA/ROCm tensors (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def workspace(nbytes, device):
+    """Per-device scratch, grown on demand; all kernels of a step run on one stream,
+    so one buffer serves every two-stage reduction / split-K slab in turn."""
+    key = (device.type, device.index)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        nbytes = max(int(nbytes), 1 << 20)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def reserve_workspace(nbytes, device):
+    """Pre-size the scratch buffer (call before HIP-graph capture)."""
+    return workspace(nbytes, device)
+
+
+# ---------------------------------------------------------------- convolutions
+def conv5x5_fwd(x, w, bias, stride):
+    lib = _lib.load()
+    _req(x, "x"), _req(w, "w")
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    if w.shape != (Cout, Cin, 5, 5):
+        raise RuntimeError(f"conv5x5_fwd: weight {tuple(w.shape)} does not match input channels {Cin}")
+    if bias is not None:
+        _req(bias, "bias")
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
+    check(lib.vg_conv5x5_fwd(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W, Cout, stride,
+                             _stream()), "vg_conv5x5_fwd")
+    return y
+
+
+def convT5x5_fwd(x, w, bias, stride):
+    """w is (Cin, Cout, 5, 5); output is (B, Cout, stride*H, stride*W)."""
+    lib = _lib.load()
+    _req(x, "x"), _req(w, "w")
+    B, Cin, H, W = x.shape
+    Cout = w.shape[1]
+    if w.shape != (Cin, Cout, 5, 5):
+        raise RuntimeError(f"convT5x5_fwd: weight {tuple(w.shape)} does not match input channels {Cin}")
+    if bias is not None:
+        _req(bias, "bias")
+    y = torch.empty((B, Cout, H * stride, W * stride), dtype=torch.float32, device=x.device)
+    check(lib.vg_convT5x5_fwd(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W, Cout, stride,
+                              _stream()), "vg_convT5x5_fwd")
+    return y
+
+
+def conv5x5_wgrad(x, gy, stride, out=None):
+    """dw[Cout,Cin,5,5] for y = conv(x, w, stride); x (B,Cin,H,W), gy (B,Cout,OH,OW)."""
+    lib = _lib.load()
+    _req(x, "x"), _req(gy, "gy")
+    B, Cin, H, W = x.shape
+    Cout = gy.shape[1]
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if gy.shape != (B, Cout, OH, OW):
+        raise RuntimeError(f"conv5x5_wgrad: gy {tuple(gy.shape)} does not match x {tuple(x.shape)} stride {stride}")
+    dw = out if out is not None else torch.empty((Cout, Cin, 5, 5), dtype=torch.float32, device=x.device)
+    need = lib.vg_conv5x5_wgrad_workspace_bytes(B, Cin, H, W, Cout, stride)
+    ws = workspace(need, x.device)
+    check(lib.vg_conv5x5_wgrad(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout, stride,
+                               ws.data_ptr(), ws.numel(), _stream()), "vg_conv5x5_wgrad")
+    return dw
+
+
+def channel_sum(g):
+    lib = _lib.load()
+    _req(g, "g")
+    B, C = g.shape[0], g.shape[1]
+    HW = g.numel() // (B * C)
+    out = torch.empty(C, dtype=torch.float32, device=g.device)
+    ws = workspace(lib.vg_bn_workspace_bytes(C), g.device)
+    check(lib.vg_channel_sum(g.data_ptr(), out.data_ptr(), B, C, HW, ws.data_ptr(), ws.numel(), _stream()),
+          "vg_channel_sum")
+    return out
+
+
+# ------------------------------------------------------------------- BatchNorm
+def bn_act_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, act):
+    lib = _lib.load()
+    _req(x, "x"), _req(gamma, "gamma"), _req(beta, "beta")
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    y = torch.empty_like(x)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = workspace(lib.vg_bn_workspace_bytes(C), x.device)
+    check(lib.vg_bn_act_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(running_mean),
+                            _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), B, C, HW, eps, momentum, act,
+                            ws.data_ptr(), ws.numel(), _stream()), "vg_bn_act_fwd")
+    return y, mean, invstd
+
+
+def bn_act_bwd(gy, x, gamma, beta, mean, invstd, act, need_param_grads=True):
+    lib = _lib.load()
+    _req(gy, "gy"), _req(x, "x")
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    gx = torch.empty_like(x)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if need_param_grads else None
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if need_param_grads else None
+    ws = workspace(lib.vg_bn_workspace_bytes(C), x.device)
+    check(lib.vg_bn_act_bwd(gy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+                            invstd.data_ptr(), gx.data_ptr(), _ptr(dgamma), _ptr(dbeta), B, C, HW, act,
+                            ws.data_ptr(), ws.numel(), _stream()), "vg_bn_act_bwd")
+    return gx, dgamma, dbeta
+
+
+# ----------------------------------------------------------------- elementwise
+def bias_act_fwd(x, bias, kind):
+    lib = _lib.load()
+    _req(x, "x")
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    y = torch.empty_like(x)
+    check(lib.vg_bias_act_fwd(x.data_ptr(), _ptr(bias), y.data_ptr(), B, C, HW, kind, _stream()),
+          "vg_bias_act_fwd")
+    return y
+
+
+def act_bwd(gy, y, kind):
+    lib = _lib.load()
+    _req(gy, "gy"), _req(y, "y")
+    gx = torch.empty_like(y)
+    check(lib.vg_act_bwd(gy.data_ptr(), y.data_ptr(), gx.data_ptr(), y.numel(), kind, _stream()), "vg_act_bwd")
+    return gx
+
+
+# ---------------------------------------------------------------------- losses
+def reparam_kl_fwd(mu, logvar, eps, beta, want_rows=False):
+    lib = _lib.load()
+    _req(mu, "mu"), _req(logvar, "logvar"), _req(eps, "eps")
+    B, D = mu.shape
+    z = torch.empty_like(mu)
+    kl = torch.empty((), dtype=torch.float32, device=mu.device)
+    rows = torch.empty(B, dtype=torch.float32, device=mu.device) if want_rows else None
+    check(lib.vg_reparam_kl_fwd(mu.data_ptr(), logvar.data_ptr(), eps.data_ptr(), z.data_ptr(), kl.data_ptr(),
+                                _ptr(rows), B, D, float(beta), _stream()), "vg_reparam_kl_fwd")
+    return z, kl, rows
+
+
+def reparam_kl_bwd(gz, mu, logvar, eps, gkl, beta):
+    lib = _lib.load()
+    B, D = mu.shape
+    gmu, glv = torch.empty_like(mu), torch.empty_like(mu)
+    check(lib.vg_reparam_kl_bwd(_ptr(gz), mu.data_ptr(), logvar.data_ptr(), eps.data_ptr(), float(gkl), float(beta),
+                                gmu.data_ptr(), glv.data_ptr(), B, D, _stream()), "vg_reparam_kl_bwd")
+    return gmu, glv
+
+
+def sqdiff_loss(a, b, scale, gscale=1.0, want_grad=True):
+    lib = _lib.load()
+    _req(a, "a"), _req(b, "b")
+    if a.shape != b.shape:
+        raise RuntimeError("sqdiff_loss: shape mismatch")
+    loss = torch.empty((), dtype=torch.float32, device=a.device)
+    ga = torch.empty_like(a) if want_grad else None
+    ws = workspace(lib.vg_sqdiff_workspace_bytes(a.numel()), a.device)
+    check(lib.vg_sqdiff_loss(a.data_ptr(), b.data_ptr(), loss.data_ptr(), _ptr(ga), a.numel(), float(scale),
+                             float(gscale), ws.data_ptr(), ws.numel(), _stream()), "vg_sqdiff_loss")
+    return loss, ga
+
+
+def bce_loss(p, target, divisor=None, gscale=1.0, want_grad=True):
+    lib = _lib.load()
+    _req(p, "p")
+    B = p.numel()
+    loss = torch.empty((), dtype=torch.float32, device=p.device)
+    gp = torch.empty_like(p) if want_grad else None
+    check(lib.vg_bce_loss(p.data_ptr(), float(target), loss.data_ptr(), _ptr(gp), B,
+                          float(divisor if divisor is not None else B), float(gscale), _stream()), "vg_bce_loss")
+    return loss, gp

@@ -1,0 +1,131 @@
+/* vaegan_hip.h -- C ABI of libvaegan_hip.so: the MI355X (gfx950) kernels behind
+ * the CelebA 64x64 beta-VAE-GAN training iteration.
+ *
+ * The reference (RicoFio/disentangle_mlp) has no FFI of its own: its hot path is
+ * Python torch.nn modules (models/model.py) whose arithmetic is dispatched to
+ * ATen.  Each entry point below replaces one ATen call site of that path; the
+ * citation next to it is the reference line that reaches the op.  A maintainer
+ * binds them with ctypes (INTEGRATION.md shows the stub) -- no torch types
+ * cross this boundary, only device pointers, sizes and a hipStream_t.
+ *
+ * Conventions
+ *   - all tensors are contiguous fp32, NCHW (activations), (Cout,Cin,5,5)
+ *     (Conv2d weights), (Cin,Cout,5,5) (ConvTranspose2d weights), (out,in)
+ *     (Linear weights): exactly the reference's state_dict layouts.
+ *   - kernels never allocate; outputs / workspaces are caller-owned device
+ *     buffers; `stream` is a hipStream_t (NULL = default stream).
+ *   - every function returns 0 on success, VG_ERR_BAD_ARG (-1) for a rejected
+ *     argument, VG_ERR_WORKSPACE (-2) for a too-small workspace, otherwise the
+ *     hipError_t of the failed launch.  No exceptions cross the ABI.
+ *   - launches are asynchronous, hold no global mutable state and are
+ *     HIP-graph capturable.
+ */
+#ifndef VAEGAN_HIP_H
+#define VAEGAN_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VG_ERR_BAD_ARG (-1)
+#define VG_ERR_WORKSPACE (-2)
+
+/* activation codes for the fused BatchNorm kernels */
+#define VG_ACT_NONE 0
+#define VG_ACT_RELU 1  /* nn.ReLU          model.py:452,463,493 */
+#define VG_ACT_LRELU 2 /* nn.LeakyReLU(.2) model.py:391,404     */
+
+int vg_version(void);
+
+/* ---- 5x5 convolutions, padding 2, stride 1 or 2 ----------------------------
+ * y[B,Cout,OH,OW] = conv2d(x[B,Cin,H,W], w[Cout,Cin,5,5]) + bias;  OH=(H-1)/s+1.
+ * nn.Conv2d forward: model.py:450,453,456 (encoder), :389,392,395,398 (discr.).
+ * Also the input gradient of vg_convT5x5_fwd.  bias may be NULL. */
+int vg_conv5x5_fwd(const float* x, const float* w, const float* bias, float* y,
+                   int B, int Cin, int H, int W, int Cout, int stride, void* stream);
+
+/* y[B,Cout,s*H,s*W] = conv_transpose2d(x[B,Cin,H,W], w[Cin,Cout,5,5], stride s,
+ * padding 2, output_padding s-1) + bias.  nn.ConvTranspose2d forward with the
+ * literal output_size of model.py:558-564 (deconv1..4, :495-507).  Also the
+ * input gradient of vg_conv5x5_fwd (then w is the Conv2d weight [Cout,Cin,5,5]
+ * read as [Cin_T=Cout, Cout_T=Cin], H*s must equal the conv input size). */
+int vg_convT5x5_fwd(const float* x, const float* w, const float* bias, float* y,
+                    int B, int Cin, int H, int W, int Cout, int stride, void* stream);
+
+/* dw[Cout,Cin,5,5] = sum_{b,oh,ow} gy[b,co,oh,ow] * x[b,ci,s*oh+kh-2,s*ow+kw-2].
+ * Weight gradient of nn.Conv2d (autograd of model.py:450...; new_betavaegan.py:103,121)
+ * and, with the roles swapped (x := gy_T, gy := x_T), of nn.ConvTranspose2d.
+ * x is [B,Cin,H,W], gy is [B,Cout,OH,OW] with OH=(H-1)/s+1.  Deterministic:
+ * split-K partial slabs in `workspace` are summed in a fixed order. */
+size_t vg_conv5x5_wgrad_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride);
+int vg_conv5x5_wgrad(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W,
+                     int Cout, int stride, void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[c] = sum_{b,hw} g[b,c,hw]   (bias gradient of the convolutions).
+ * workspace >= vg_bn_workspace_bytes(C). */
+int vg_channel_sum(const float* g, float* out, int B, int C, int HW,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- train-mode BatchNorm (+ReLU / LeakyReLU(0.2)) --------------------------
+ * x is [B,C,HW] (HW=1 for BatchNorm1d).  Batch statistics (biased variance,
+ * eps), y = act(gamma*(x-mean)*invstd + beta); running_mean/var updated with
+ * `momentum` (unbiased variance), as F.batch_norm(training=True) does.
+ * nn.BatchNorm2d/1d in train mode: model.py:451-458,462,468,492,496-505,390-400
+ * (the reference never calls .eval()).  save_mean / save_invstd ([C]) are kept
+ * for the backward.  running_mean / running_var may be NULL.
+ * workspace >= vg_bn_workspace_bytes(C). */
+size_t vg_bn_workspace_bytes(int C);
+int vg_bn_act_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                  float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                  int B, int C, int HW, float eps, float momentum, int act,
+                  void* workspace, size_t workspace_bytes, void* stream);
+/* gx, dgamma, dbeta from gy, the saved x and statistics (the activation mask is
+ * recomputed from x, bit-identically to the forward). gx must not alias gy. */
+int vg_bn_act_bwd(const float* gy, const float* x, const float* gamma, const float* beta,
+                  const float* save_mean, const float* save_invstd,
+                  float* gx, float* dgamma, float* dbeta,
+                  int B, int C, int HW, int act,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- elementwise activations ------------------------------------------------
+ * LeakyReLU(0.2) after lth_features (model.py:404), tanh after deconv4
+ * (model.py:509,565), both with an optional per-channel bias add fused in:
+ * y = act(x + bias[c]) for x [B,C,HW]; bias may be NULL. */
+int vg_bias_act_fwd(const float* x, const float* bias, float* y, int B, int C, int HW, int act_kind, void* stream);
+int vg_act_bwd(const float* gy, const float* y, float* gx, size_t n, int act_kind, void* stream);
+#define VG_EW_LRELU 0
+#define VG_EW_TANH 1
+#define VG_EW_SIGMOID 2
+
+/* ---- fused losses -----------------------------------------------------------
+ * Loss scalars are written to device memory (no host sync). */
+
+/* z = mu + eps*exp(logvar/2) (model.py:532-535) and
+ * kl[0] = beta * (-0.5 * sum(1 + logvar - mu^2 - exp(logvar))) (new_betavaegan.py:64-65);
+ * kl_rows ([B], may be NULL) gets the un-scaled per-sample KL (model.py:321). */
+int vg_reparam_kl_fwd(const float* mu, const float* logvar, const float* eps, float* z, float* kl,
+                      float* kl_rows, int B, int D, float beta, void* stream);
+/* gmu = gz + gkl*beta*mu ; glogvar = gz*eps*0.5*exp(logvar/2) + gkl*beta*0.5*(exp(logvar)-1).
+ * gz may be NULL (treated as 0). */
+int vg_reparam_kl_bwd(const float* gz, const float* mu, const float* logvar, const float* eps,
+                      float gkl, float beta, float* gmu, float* glogvar, int B, int D, void* stream);
+
+/* loss[0] = scale * sum((a-b)^2);  ga = gscale * 2*scale*(a-b)  (ga may be NULL).
+ * scale=0.5: Dis_l / SIM (new_betavaegan.py:67-69); scale=1: pixel MSE (:71-75). */
+int vg_sqdiff_loss(const float* a, const float* b, float* loss, float* ga, size_t n,
+                   float scale, float gscale, void* workspace, size_t workspace_bytes, void* stream);
+size_t vg_sqdiff_workspace_bytes(size_t n);
+
+/* nn.BCELoss() against a constant label (new_betavaegan.py:53,101,118,153-154):
+ * loss[0] = (1/divisor) * sum(-(t*max(log p,-100) + (1-t)*max(log(1-p),-100)));
+ * gp = gscale/divisor * (p-t)/max(p*(1-p),1e-12)   (gp may be NULL).
+ * divisor = B locally; the global batch under data parallelism. */
+int vg_bce_loss(const float* p, float target, float* loss, float* gp, int B, float divisor,
+                float gscale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAEGAN_HIP_H */

@@ -1,0 +1,222 @@
+"""GPU parity: every C-ABI kernel against the oracle (fp64 CPU restatement of the
+reference's ATen ops) and the committed golden KATs.  fp32 path, exact-fp32 MFMA:
+tolerance = relative L2 error <= 2e-6 * sqrt(K/64 + 1) style bounds written per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    from disentangle_mlp_amd import ops
+    return ops
+
+
+def dev(a):
+    return torch.as_tensor(np.asarray(a), dtype=torch.float32).cuda().contiguous()
+
+
+def rel_l2(a, ref):
+    a, ref = a.detach().cpu().double(), ref.detach().cpu().double()
+    return float((a - ref).norm() / max(ref.norm(), 1e-30))
+
+
+def assert_close(a, ref, tol, what=""):
+    assert tuple(a.shape) == tuple(ref.shape), (what, a.shape, ref.shape)
+    e = rel_l2(a, ref)
+    assert math.isfinite(e) and e <= tol, f"{what}: rel L2 {e:.3e} > {tol:.1e}"
+    m = float((a.detach().cpu().double() - ref.double()).abs().max())
+    assert m <= 50 * tol * float(ref.abs().max()) + 1e-30, f"{what}: max abs err {m:.3e}"
+
+
+# ------------------------------------------------------------------ golden KATs
+@pytest.mark.parametrize("tag,stride", [("conv_s2", 2), ("conv_s1", 1), ("conv_s2b", 2)])
+def test_conv_kats(H, kats, tag, stride):
+    x, w, b, gy = (dev(kats[f"{tag}/{k}"]) for k in ("x", "w", "b", "gy"))
+    y = H.conv5x5_fwd(x, w, b, stride)
+    assert_close(y, torch.from_numpy(kats[f"{tag}/y"]), 2e-6, tag + " fwd")
+    if x.shape[2] % stride == 0:
+        gx = H.convT5x5_fwd(gy, w, None, stride)
+        assert_close(gx, torch.from_numpy(kats[f"{tag}/gx"]), 2e-6, tag + " dgrad")
+    gw = H.conv5x5_wgrad(x, gy, stride)
+    assert_close(gw, torch.from_numpy(kats[f"{tag}/gw"]), 2e-6, tag + " wgrad")
+    gb = H.channel_sum(gy)
+    assert_close(gb, torch.from_numpy(kats[f"{tag}/gb"]), 2e-6, tag + " bgrad")
+
+
+@pytest.mark.parametrize("tag,stride", [("convT_s2", 2), ("convT_s1", 1), ("convT_s2b", 2)])
+def test_convT_kats(H, kats, tag, stride):
+    x, w, b, gy = (dev(kats[f"{tag}/{k}"]) for k in ("x", "w", "b", "gy"))
+    y = H.convT5x5_fwd(x, w, b, stride)
+    assert_close(y, torch.from_numpy(kats[f"{tag}/y"]), 2e-6, tag + " fwd")
+    gx = H.conv5x5_fwd(gy, w, None, stride)          # dgrad of convT = conv with the same weight
+    assert_close(gx, torch.from_numpy(kats[f"{tag}/gx"]), 2e-6, tag + " dgrad")
+    gw = H.conv5x5_wgrad(gy, x, stride)              # roles swapped
+    assert_close(gw, torch.from_numpy(kats[f"{tag}/gw"]), 2e-6, tag + " wgrad")
+
+
+@pytest.mark.parametrize("tag,act", [("bn2d_relu", 1), ("bn2d_lrelu", 2), ("bn1d_relu", 1)])
+def test_bn_kats(H, kats, tag, act):
+    x, w, b, gy = (dev(kats[f"{tag}/{k}"]) for k in ("x", "w", "b", "gy"))
+    C = x.shape[1]
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    y, mean, invstd = H.bn_act_fwd(x, w, b, rm, rv, 1e-5, 0.1, act)
+    assert_close(y, torch.from_numpy(kats[f"{tag}/y"]), 2e-6, tag + " y")
+    assert_close(rm, torch.from_numpy(kats[f"{tag}/rm"]), 2e-6, tag + " running_mean")
+    assert_close(rv, torch.from_numpy(kats[f"{tag}/rv"]), 2e-6, tag + " running_var")
+    gx, gw, gb = H.bn_act_bwd(gy, x, w, b, mean, invstd, act)
+    assert_close(gx, torch.from_numpy(kats[f"{tag}/gx"]), 5e-6, tag + " gx")
+    assert_close(gw, torch.from_numpy(kats[f"{tag}/gw"]), 5e-6, tag + " dgamma")
+    assert_close(gb, torch.from_numpy(kats[f"{tag}/gb"]), 5e-6, tag + " dbeta")
+
+
+def test_loss_kats(H, kats):
+    mu, lv, eps, gz = (dev(kats[f"rkl/{k}"]) for k in ("mu", "lv", "eps", "gz"))
+    z, kl, rows = H.reparam_kl_fwd(mu, lv, eps, 25.0, want_rows=True)
+    assert_close(z, torch.from_numpy(kats["rkl/z"]), 2e-6, "z")
+    assert abs(float(kl) - float(kats["rkl/kl"])) <= 2e-6 * abs(float(kats["rkl/kl"]))
+    assert abs(float(rows.sum()) * 25.0 - float(kats["rkl/kl"])) <= 1e-5 * abs(float(kats["rkl/kl"]))
+    gmu, glv = H.reparam_kl_bwd(gz, mu, lv, eps, 1.0, 25.0)
+    assert_close(gmu, torch.from_numpy(kats["rkl/gmu"]), 2e-6, "gmu")
+    assert_close(glv, torch.from_numpy(kats["rkl/glv"]), 2e-6, "glv")
+    for tag, scale in (("disl", 0.5), ("mse", 1.0)):
+        a, b = dev(kats[f"{tag}/a"]), dev(kats[f"{tag}/b"])
+        l, ga = H.sqdiff_loss(a, b, scale)
+        assert abs(float(l) - float(kats[f"{tag}/l"])) <= 2e-6 * abs(float(kats[f"{tag}/l"]))
+        assert_close(ga, torch.from_numpy(kats[f"{tag}/ga"]), 2e-6, tag + " grad")
+    for y in (0.9, 0.1):
+        p = dev(kats[f"bce{y}/p"])
+        l, gp = H.bce_loss(p, y)
+        assert abs(float(l) - float(kats[f"bce{y}/l"])) <= 1e-5 * abs(float(kats[f"bce{y}/l"])), (float(l), kats[f"bce{y}/l"])
+        ref = torch.from_numpy(kats[f"bce{y}/gp"]).double()
+        got = gp.cpu().double()
+        assert torch.allclose(got, ref, rtol=1e-5, atol=0), (got, ref)
+    t = dev(kats["tanh/x"])
+    ty = H.bias_act_fwd(t.view(3, 7, 1), None, 1).view(3, 7)
+    assert_close(ty, torch.from_numpy(kats["tanh/y"]), 2e-6, "tanh")
+    tg = H.act_bwd(dev(kats["tanh/gy"]), ty, 1)
+    assert_close(tg, torch.from_numpy(kats["tanh/gx"]), 5e-6, "tanh bwd")
+
+
+# ---------------------------------------------------- the reference's layer shapes
+CONV_LAYERS = [  # (Cin, Cout, H, stride)  model.py:450-456 (enc), :389-398 (dis)
+    (3, 64, 64, 2), (64, 128, 32, 2), (128, 256, 16, 2),
+    (3, 32, 64, 1), (32, 128, 64, 2), (128, 256, 32, 2), (256, 256, 16, 2),
+]
+CONVT_LAYERS = [  # (Cin, Cout, H, stride)  model.py:495-507
+    (256, 256, 8, 2), (256, 128, 16, 2), (128, 32, 32, 2), (32, 3, 64, 1),
+]
+
+
+def _rand(*s, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*s, generator=g)
+
+
+@pytest.mark.parametrize("Cin,Cout,Hs,stride", CONV_LAYERS)
+@pytest.mark.parametrize("B", [3])
+def test_conv_layers(H, Cin, Cout, Hs, stride, B):
+    x, w, b = _rand(B, Cin, Hs, Hs, seed=1), 0.05 * _rand(Cout, Cin, 5, 5, seed=2), _rand(Cout, seed=3)
+    y_ref = O.conv5x5(x, w, b, stride)
+    y = H.conv5x5_fwd(x.cuda(), w.cuda(), b.cuda(), stride)
+    tol = 3e-6
+    assert_close(y, y_ref, tol, "conv fwd")
+    gy = _rand(*y_ref.shape, seed=4)
+    gx_ref, gw_ref = O.conv5x5_grads(x, w, gy, stride)
+    gx = H.convT5x5_fwd(gy.cuda(), w.cuda(), None, stride)
+    assert_close(gx, gx_ref, tol, "conv dgrad")
+    gw = H.conv5x5_wgrad(x.cuda(), gy.cuda(), stride)
+    assert_close(gw, gw_ref, tol, "conv wgrad")
+
+
+@pytest.mark.parametrize("Cin,Cout,Hs,stride", CONVT_LAYERS)
+@pytest.mark.parametrize("B", [3])
+def test_convT_layers(H, Cin, Cout, Hs, stride, B):
+    x, w, b = _rand(B, Cin, Hs, Hs, seed=5), 0.05 * _rand(Cin, Cout, 5, 5, seed=6), _rand(Cout, seed=7)
+    y_ref = O.convT5x5(x, w, b, stride)
+    y = H.convT5x5_fwd(x.cuda(), w.cuda(), b.cuda(), stride)
+    tol = 3e-6
+    assert_close(y, y_ref, tol, "convT fwd")
+    gy = _rand(*y_ref.shape, seed=8)
+    gx_ref, gw_ref = O.convT5x5_grads(x, w, gy, stride)
+    gx = H.conv5x5_fwd(gy.cuda(), w.cuda(), None, stride)
+    assert_close(gx, gx_ref, tol, "convT dgrad")
+    gw = H.conv5x5_wgrad(gy.cuda(), x.cuda(), stride)
+    assert_close(gw, gw_ref, tol, "convT wgrad")
+
+
+@pytest.mark.parametrize("B,Cin,Cout,Hs,Ws,stride", [
+    (1, 1, 1, 6, 6, 2), (1, 1, 1, 5, 7, 1), (5, 7, 33, 12, 20, 2), (2, 5, 65, 10, 6, 1), (7, 2, 130, 4, 4, 2),
+    (2, 9, 3, 40, 72, 2),
+])
+def test_conv_ragged(H, B, Cin, Cout, Hs, Ws, stride):
+    """Ragged shapes: tiles partly outside the image, channel counts off the tile grid."""
+    x, w, b = _rand(B, Cin, Hs, Ws, seed=9), _rand(Cout, Cin, 5, 5, seed=10), _rand(Cout, seed=11)
+    y_ref = O.conv5x5(x, w, b, stride)
+    assert_close(H.conv5x5_fwd(x.cuda(), w.cuda(), b.cuda(), stride), y_ref, 3e-6, "fwd")
+    gy = _rand(*y_ref.shape, seed=12)
+    gx_ref, gw_ref = O.conv5x5_grads(x, w, gy, stride)
+    assert_close(H.conv5x5_wgrad(x.cuda(), gy.cuda(), stride), gw_ref, 3e-6, "wgrad")
+    if Hs % stride == 0 and Ws % stride == 0:
+        assert_close(H.convT5x5_fwd(gy.cuda(), w.cuda(), None, stride), gx_ref, 3e-6, "dgrad")
+    # transposed conv with the same tensors: x2 (B,Cout,oh,ow) -> (B,Cin,s*oh,s*ow)
+    wt = _rand(Cout, Cin, 5, 5, seed=13)
+    yt_ref = O.convT5x5(gy, wt, None, stride)
+    assert_close(H.convT5x5_fwd(gy.cuda(), wt.cuda(), None, stride), yt_ref, 3e-6, "convT fwd")
+
+
+@pytest.mark.parametrize("shape,act", [((8, 32, 64, 64), "lrelu"), ((8, 256, 8, 8), "relu"), ((5, 7, 3, 5), "none"),
+                                       ((16, 2048), "relu"), ((128, 16384), "relu"), ((16, 3, 1, 1), "lrelu")])
+def test_bn_shapes(H, shape, act):
+    x = _rand(*shape, seed=20) * 2 + 0.5
+    C = shape[1]
+    gamma, beta = 1 + 0.1 * _rand(C, seed=21), 0.1 * _rand(C, seed=22)
+    gy = _rand(*shape, seed=23)
+    ref = O.bn_act(x, gamma, beta, act, gy=gy)
+    code = {"none": 0, "relu": 1, "lrelu": 2}[act]
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    y, mean, invstd = H.bn_act_fwd(x.cuda(), gamma.cuda(), beta.cuda(), rm, rv, 1e-5, 0.1, code)
+    assert_close(y, ref["y"], 3e-6, "y")
+    assert_close(rm, ref["rm"], 3e-6, "rm")
+    assert_close(rv, ref["rv"], 3e-6, "rv")
+    gx, gw, gb = H.bn_act_bwd(gy.cuda(), x.cuda(), gamma.cuda(), beta.cuda(), mean, invstd, code)
+    assert_close(gx, ref["gx"], 2e-5, "gx")
+    assert_close(gw, ref["gw"], 2e-5, "dgamma")
+    assert_close(gb, ref["gb"], 2e-5, "dbeta")
+
+
+def test_losses_full_size(H):
+    """BASELINE B=128 sizes; linearity / symmetry properties + oracle values."""
+    a, b = _rand(128, 3, 64, 64, seed=30), _rand(128, 3, 64, 64, seed=31)
+    l, ga = H.sqdiff_loss(a.cuda(), b.cuda(), 1.0)
+    ref = float(((a.double() - b.double()) ** 2).sum())
+    assert abs(float(l) - ref) <= 2e-6 * ref
+    assert_close(ga, 2 * (a.double() - b.double()), 1e-6, "mse grad")
+    l2, _ = H.sqdiff_loss(b.cuda(), a.cuda(), 1.0, want_grad=False)
+    assert float(l2) == float(l)                       # symmetric, deterministic
+    l0, g0 = H.sqdiff_loss(a.cuda(), a.cuda(), 0.5)
+    assert float(l0) == 0.0 and float(g0.abs().max()) == 0.0
+    mu, lv, eps = _rand(128, 128, seed=32), 0.3 * _rand(128, 128, seed=33), _rand(128, 128, seed=34)
+    z, kl, rows = H.reparam_kl_fwd(mu.cuda(), lv.cuda(), eps.cuda(), 25.0, want_rows=True)
+    md, ld = mu.double(), lv.double()
+    ref_rows = -0.5 * (1 + ld - md ** 2 - ld.exp()).sum(1)
+    assert_close(rows, ref_rows, 2e-6, "kl rows")
+    assert abs(float(kl) - 25.0 * float(ref_rows.sum())) <= 2e-6 * abs(25.0 * float(ref_rows.sum()))
+    assert_close(z, md + eps.double() * (0.5 * ld).exp(), 1e-6, "z")
+    zk, klz, _ = H.reparam_kl_fwd(torch.zeros(4, 128).cuda(), torch.zeros(4, 128).cuda(), eps[:4].cuda(), 25.0)
+    assert float(klz) == 0.0                            # KL(N(0,1)||N(0,1)) = 0
+    p = torch.sigmoid(_rand(128, seed=35))
+    lb, gp = H.bce_loss(p.cuda(), 0.9)
+    ref = torch.nn.functional.binary_cross_entropy(p.double(), torch.full((128,), 0.9, dtype=torch.float64))
+    assert abs(float(lb) - float(ref)) <= 1e-5 * float(ref)
+
+
+def test_rejects_cpu_tensors(H):
+    with pytest.raises(RuntimeError):
+        H.conv5x5_fwd(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 5, 5), None, 2)
