@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CelebA 64x64 beta-VAE-GAN training iteration (encoder + decoder +
+discriminator, three optimizer steps; experiments/new_betavaegan.py:87-193 of the
+reference) in images/s on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 128]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU; per-GPU batch 128 (BASELINE.json configs[1] at N=1; configs[2]
+= global batch 1024 at N=8: weak scaling).  Synthetic data (U(-1,1) images, N(0,1)
+noise) resident in HBM before the timed region; weights from the reference's seed
+recipe.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak (spec)
+ALG_GFLOP_PER_IMAGE = 20.075       # BASELINE.md section 2 (necessary passes only)
+ALG_CONV_GFLOP_PER_IMAGE = 18.488
+
+
+def conv_flops(key):
+    """Algorithmic FLOPs of one launch: 2 * MACs (5x5 taps; transposed conv counts its
+    real taps, i.e. the same MACs as the convolution it transposes)."""
+    op, B, Cin, H, W, Cout, s = key
+    if op == "convT_fwd":        # x (B,Cin,H,W) -> (B,Cout,sH,sW): every input pixel meets 25 taps
+        return 2.0 * B * H * W * Cin * Cout * 25
+    oh, ow = (H - 1) // s + 1, (W - 1) // s + 1
+    return 2.0 * B * oh * ow * Cin * Cout * 25   # conv_fwd and conv_wgrad
+
+
+def cpu_baseline(batch, beta):
+    """The oracle (CPU restatement of the reference's path) timed on this host's cores on a
+    bounded sample: one iteration at the benchmark's per-GPU batch after a small warm-up."""
+    from oracle import steps as osteps
+    # the GPU box gives one job a 16-core share of the host; more threads only oversubscribe
+    threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 16)
+    torch.set_num_threads(threads)
+    eg, d, oeg, od = osteps.build_nets()
+    wb = osteps.synthetic_batch(8)
+    osteps.betavaegan_step(eg, d, oeg, od, wb["data"], wb["noise"], wb["eps2"], wb["eps3"], beta=beta)
+    b = osteps.synthetic_batch(batch)
+    t0 = time.perf_counter()
+    osteps.betavaegan_step(eg, d, oeg, od, b["data"], b["noise"], b["eps2"], b["eps3"], beta=beta)
+    dt = time.perf_counter() - t0
+    return {"value": round(batch / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"1 full beta-VAE-GAN iteration at batch {batch} (after a batch-8 warm-up), "
+                      f"torch CPU fp32, {threads} threads, {dt:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
+    ap.add_argument("--beta", type=float, default=25.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from disentangle_mlp_amd import ops
+    from disentangle_mlp_amd.trainer import BetaVAEGANTrainer
+
+    B = args.batch
+    tr = BetaVAEGANTrainer(device=dev, seed=999, beta=args.beta)
+    g = torch.Generator().manual_seed(1234 + rank)            # each rank its own shard
+    data = (torch.rand(B, 3, 64, 64, generator=g) * 2 - 1).to(dev)
+    noise = [torch.randn(B, 128, generator=g).to(dev) for _ in range(3)]
+
+    def one_step():
+        return tr.step(data, noise[0], noise[1], noise[2], real_label=0.9, fake_label=0.1)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- warm-up; the last warm-up step times every convolution launch to find the dominant one
+    for i in range(max(args.warmup, 1)):
+        if i == max(args.warmup, 1) - 1:
+            ops.start_timing()
+        one_step()
+    per_key = ops.stop_timing()
+    totals = {k: sum(v) for k, v in per_key.items()}
+    dominant = max(totals, key=totals.get) if totals else None
+    conv_ms_profiled = sum(totals.values())
+
+    # ---- timed region: exactly K steps, dominant kernel bracketed by HIP events
+    fence()
+    ops.start_timing(only=dominant)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dom_ms = ops.stop_timing().get(dominant, [])
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    finite = all(bool(torch.isfinite(v).all()) for v in out.values())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = B * world * args.steps / elapsed
+        roof = None
+        if dominant and dom_ms:
+            avg_ms = sum(dom_ms) / len(dom_ms)
+            ach = conv_flops(dominant) / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "kernel": "conv5x5_igemm_kernel" if dominant[0] != "conv_wgrad" else "conv5x5_wgrad_kernel",
+                    "launch": {"op": dominant[0], "B": dominant[1], "Cin": dominant[2], "H": dominant[3],
+                               "W": dominant[4], "Cout": dominant[5], "stride": dominant[6]},
+                    "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(dom_ms),
+                    "alg_gflop_per_launch": round(conv_flops(dominant) / 1e9, 3)}
+        res = {
+            "metric": "celeba64_betavaegan_train_images_per_sec", "value": round(value, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32",
+            "data": "synthetic",
+            "config": {"workload": "new_betavaegan.py beta=25 VAE-GAN iteration (D + decoder + encoder phases, "
+                                   "3 Adam steps), CelebA 64x64, per-GPU batch %d" % B,
+                       "global_batch": B * world, "per_gpu_batch": B, "beta": args.beta,
+                       "parallelism": "dp%d" % world},
+            "roofline": roof,
+            "step_tflops_algorithmic": round(ALG_GFLOP_PER_IMAGE * value / 1e3, 2),
+            "conv_path_frac_of_fp32_mfma_peak": round(ALG_CONV_GFLOP_PER_IMAGE * value / world / 1e3
+                                                      / PEAK_FP32_MFMA_TFLOPS, 4),
+            "conv_ms_per_step_profiled": round(conv_ms_profiled, 3),
+            "losses_finite": finite,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(B, args.beta)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,10 @@ import ctypes
 import os
 from ctypes import c_float, c_int, c_size_t, c_void_p
 
+# torch must be imported first: its bundled HIP runtime (libamdhip64) then serves this
+# library too, so kernels launch in the same HIP context that owns the tensors' memory.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvaegan_hip.so")
 
@@ -27,7 +31,8 @@ SIGNATURES = {
     "vg_bias_act_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "vg_act_bwd": (_I, [_P, _P, _P, _Z, _I, _P]),
     "vg_reparam_kl_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
-    "vg_reparam_kl_bwd": (_I, [_P, _P, _P, _P, _F, _F, _P, _P, _I, _I, _P]),
+    "vg_reparam_kl_bwd": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _P]),
+    "vg_scale_by_scalar": (_I, [_P, _P, _P, _Z, _P]),
     "vg_sqdiff_workspace_bytes": (_Z, [_Z]),
     "vg_sqdiff_loss": (_I, [_P, _P, _P, _P, _Z, _F, _F, _P, _Z, _P]),
     "vg_bce_loss": (_I, [_P, _F, _P, _P, _I, _F, _F, _P]),

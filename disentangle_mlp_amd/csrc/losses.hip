@@ -101,11 +101,11 @@ __global__ __launch_bounds__(1024) void reparam_kl_fwd_kernel(const float* __res
 
 __global__ __launch_bounds__(NT) void reparam_kl_bwd_kernel(const float* __restrict__ gz, const float* __restrict__ mu,
                                                             const float* __restrict__ lv,
-                                                            const float* __restrict__ eps, float gkl, float beta,
+                                                            const float* __restrict__ eps, const float* __restrict__ gkl, float beta,
                                                             float* __restrict__ gmu, float* __restrict__ glv,
                                                             size_t n) {
   const size_t stride = (size_t)gridDim.x * NT;
-  const float kb = gkl * beta;
+  const float kb = (gkl ? gkl[0] : 0.f) * beta;
   for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) {
     const float g = gz ? gz[i] : 0.f;
     const float l = lv[i];
@@ -160,6 +160,19 @@ __global__ __launch_bounds__(NT) void bce_kernel(const float* __restrict__ p, fl
   if (threadIdx.x == 0 && loss) loss[0] = (float)(t * inv_div);
 }
 
+__global__ __launch_bounds__(NT) void scale_by_scalar_kernel(const float* g, const float* __restrict__ s, float* out,
+                                                             size_t n) {
+  const float v = s[0];
+  const size_t stride = (size_t)gridDim.x * NT;
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += stride) {
+    float4 t = reinterpret_cast<const float4*>(g)[i];
+    t.x *= v; t.y *= v; t.z *= v; t.w *= v;
+    reinterpret_cast<float4*>(out)[i] = t;
+  }
+  for (size_t i = (n4 << 2) + (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) out[i] = g[i] * v;
+}
+
 int flat_grid(size_t n) {
   const size_t blocks = (n / 4 + NT - 1) / NT;
   return (int)(blocks > 2048 ? 2048 : (blocks < 1 ? 1 : blocks));
@@ -196,12 +209,19 @@ extern "C" int vg_reparam_kl_fwd(const float* mu, const float* logvar, const flo
   return 0;
 }
 
-extern "C" int vg_reparam_kl_bwd(const float* gz, const float* mu, const float* logvar, const float* eps, float gkl,
-                                 float beta, float* gmu, float* glogvar, int B, int D, void* stream) {
+extern "C" int vg_reparam_kl_bwd(const float* gz, const float* mu, const float* logvar, const float* eps,
+                                 const float* gkl, float beta, float* gmu, float* glogvar, int B, int D, void* stream) {
   if (!mu || !logvar || !eps || !gmu || !glogvar || B <= 0 || D <= 0) return VG_ERR_BAD_ARG;
   const size_t n = (size_t)B * D;
   hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3(flat_grid(n * 4)), dim3(NT), 0, (hipStream_t)stream, gz, mu, logvar,
                      eps, gkl, beta, gmu, glogvar, n);
+  VG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vg_scale_by_scalar(const float* g, const float* s, float* out, size_t n, void* stream) {
+  if (!g || !s || !out || n == 0) return VG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(scale_by_scalar_kernel, dim3(flat_grid(n)), dim3(NT), 0, (hipStream_t)stream, g, s, out, n);
   VG_CHECK_LAUNCH();
   return 0;
 }

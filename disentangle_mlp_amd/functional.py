@@ -1,0 +1,226 @@
+"""torch.autograd.Function wrappers: each forward / backward is one or two launches
+of the HIP library (disentangle_mlp_amd.ops).  Work that autograd reports as not
+needed (``ctx.needs_input_grad``) is skipped -- e.g. the discriminator's weight
+gradients while it only relays gradients to the decoder (SURVEY.md section 3.1
+item 3: those gradients are discarded by the reference's next ``zero_grad``).
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import ops
+
+# How the gradient of a convolution bias that feeds a train-mode BatchNorm is
+# produced.  It is analytically zero (BN subtracts the batch mean); the reference
+# accumulates pure rounding noise there.
+BIAS_GRAD_COMPUTE, BIAS_GRAD_ZERO = 0, 1
+
+
+class Conv5x5Fn(Function):
+    """nn.Conv2d(k=5, p=2, stride) -- /root/reference/models/model.py:450 etc."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, bias_grad):
+        ctx.stride, ctx.bias_grad = stride, bias_grad
+        ctx.save_for_backward(x, w)
+        return ops.conv5x5_fwd(x, w, bias, stride)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            if x.shape[2] % ctx.stride or x.shape[3] % ctx.stride:
+                raise RuntimeError("conv5x5 data gradient needs input sizes divisible by the stride")
+            gx = ops.convT5x5_fwd(gy, w, None, ctx.stride)
+        if ctx.needs_input_grad[1]:
+            gw = ops.conv5x5_wgrad(x, gy, ctx.stride)
+        if ctx.needs_input_grad[2]:
+            gb = torch.zeros(w.shape[0], dtype=gy.dtype, device=gy.device) \
+                if ctx.bias_grad == BIAS_GRAD_ZERO else ops.channel_sum(gy)
+        return gx, gw, gb, None, None
+
+
+class ConvT5x5Fn(Function):
+    """nn.ConvTranspose2d(k=5, p=2, stride, output_size=stride*in) -- model.py:495-507, :558-564."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, bias_grad):
+        ctx.stride, ctx.bias_grad = stride, bias_grad
+        ctx.save_for_backward(x, w)
+        return ops.convT5x5_fwd(x, w, bias, stride)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.conv5x5_fwd(gy, w, None, ctx.stride)
+        if ctx.needs_input_grad[1]:
+            gw = ops.conv5x5_wgrad(gy, x, ctx.stride)       # roles swapped
+        if ctx.needs_input_grad[2]:
+            gb = torch.zeros(w.shape[1], dtype=gy.dtype, device=gy.device) \
+                if ctx.bias_grad == BIAS_GRAD_ZERO else ops.channel_sum(gy)
+        return gx, gw, gb, None, None
+
+
+class BNActFn(Function):
+    """Train-mode BatchNorm1d/2d + {none, ReLU, LeakyReLU(0.2)} -- model.py:451-452 etc.
+    running_mean / running_var are updated in place by the kernel."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act):
+        y, mean, invstd = ops.bn_act_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, act)
+        ctx.act = act
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        gx, dg, db = ops.bn_act_bwd(gy.contiguous(), x, gamma, beta, mean, invstd, ctx.act, need_p)
+        return gx, dg, db, None, None, None, None, None
+
+
+class BiasActFn(Function):
+    """y = act(x + bias[c]) for LeakyReLU(0.2) / tanh / sigmoid -- model.py:404, 509, 408."""
+
+    @staticmethod
+    def forward(ctx, x, bias, kind):
+        y = ops.bias_act_fwd(x, bias, kind)
+        ctx.kind = kind
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gx = ops.act_bwd(gy.contiguous(), y, ctx.kind)
+        gb = ops.channel_sum(gx) if ctx.needs_input_grad[1] else None
+        return gx, gb, None
+
+
+class ReparamKLFn(Function):
+    """z = mu + eps*exp(logvar/2) and kl = beta*KL(q||N(0,1)) summed over the batch --
+    model.py:532-535 + experiments/new_betavaegan.py:64-65, one fused kernel each way."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps, beta):
+        z, kl, _ = ops.reparam_kl_fwd(mu, logvar, eps, beta)
+        ctx.beta = beta
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(mu, logvar, eps)
+        return z, kl
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gz, gkl):
+        mu, logvar, eps = ctx.saved_tensors
+        if gz is None and gkl is None:
+            return None, None, None, None
+        gz = gz.contiguous() if gz is not None else None
+        gkl = gkl.contiguous() if gkl is not None else None
+        gmu, glv = ops.reparam_kl_bwd(gz, mu, logvar, eps, gkl, ctx.beta)
+        return gmu, glv, None, None
+
+
+class KLRowsFn(Function):
+    """Encoder_celeba's per-sample KL (model.py:321) together with z."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        z, _, rows = ops.reparam_kl_fwd(mu, logvar, eps, 1.0, want_rows=True)
+        ctx.mark_non_differentiable(rows)
+        ctx.save_for_backward(mu, logvar, eps)
+        return z, rows
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gz, _):
+        mu, logvar, eps = ctx.saved_tensors
+        gmu, glv = ops.reparam_kl_bwd(gz.contiguous(), mu, logvar, eps, None, 1.0)
+        return gmu, glv, None
+
+
+class SqDiffLossFn(Function):
+    """scale * sum((a-b)^2), gradient to ``a`` only (``b`` is a target).
+    scale 0.5 = Dis_l / SIM (new_betavaegan.py:67-69), 1.0 = pixel MSE (:71-75)."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        loss, ga = ops.sqdiff_loss(a, b, scale, 1.0, want_grad=True)
+        ctx.save_for_backward(ga)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        (ga,) = ctx.saved_tensors
+        return ops.scale_by_scalar(ga, gout.contiguous()), None, None
+
+
+class BCELossFn(Function):
+    """nn.BCELoss() vs a constant label (new_betavaegan.py:53,97,101); ``divisor`` is the
+    batch the mean runs over (the global batch under data parallelism)."""
+
+    @staticmethod
+    def forward(ctx, p, target, divisor):
+        loss, gp = ops.bce_loss(p, target, divisor, 1.0, want_grad=True)
+        ctx.save_for_backward(gp)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        (gp,) = ctx.saved_tensors
+        return ops.scale_by_scalar(gp, gout.contiguous()), None, None
+
+
+# ------------------------------------------------------------ functional API
+def conv5x5(x, w, bias, stride, bias_grad=BIAS_GRAD_COMPUTE):
+    return Conv5x5Fn.apply(x, w, bias, stride, bias_grad)
+
+
+def conv_transpose5x5(x, w, bias, stride, bias_grad=BIAS_GRAD_COMPUTE):
+    return ConvT5x5Fn.apply(x, w, bias, stride, bias_grad)
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, act=ops.ACT_NONE):
+    return BNActFn.apply(x, gamma, beta, running_mean, running_var, eps, momentum, act)
+
+
+def bias_act(x, bias, kind):
+    return BiasActFn.apply(x, bias, kind)
+
+
+def reparam_kl(mu, logvar, eps, beta):
+    return ReparamKLFn.apply(mu, logvar, eps, float(beta))
+
+
+def kld_loss(mu, logvar, beta):
+    """KLD of experiments/new_betavaegan.py:64-65 (no sampling)."""
+    _, kl = ReparamKLFn.apply(mu, logvar, torch.zeros_like(mu), float(beta))
+    return kl
+
+
+def sim_loss(sim_recon, sim_real):
+    """SIM / Dis_l of new_betavaegan.py:67-69.  ``sim_real`` is a target (the reference
+    leaves it attached, but only the discriminator -- whose gradients are discarded
+    in that phase -- would receive anything through it)."""
+    return SqDiffLossFn.apply(sim_recon, sim_real.detach(), 0.5)
+
+
+def reconstruction_loss(recon_x, x):
+    """new_betavaegan.py:71-75."""
+    return SqDiffLossFn.apply(recon_x, x.detach(), 1.0)
+
+
+def bce_loss(p, label_value, divisor=None):
+    return BCELossFn.apply(p.contiguous(), float(label_value), divisor)

@@ -14,6 +14,48 @@ EW_LRELU, EW_TANH, EW_SIGMOID = 0, 1, 2
 
 _workspaces = {}
 
+# Optional launch timing (bench.py): when set to a dict, every convolution launch whose
+# key passes `_timing_filter` is bracketed by HIP events on the launch stream.
+_timing = None
+_timing_filter = None
+
+
+def start_timing(only=None):
+    """Collect (start, end) HIP-event pairs per convolution launch key; ``only`` restricts
+    collection to one key (dominant-kernel timing inside the timed region)."""
+    global _timing, _timing_filter
+    _timing, _timing_filter = {}, only
+
+
+def stop_timing():
+    """Returns {key: [ms, ...]} (synchronises)."""
+    global _timing, _timing_filter
+    t, _timing, _timing_filter = _timing, None, None
+    if not t:
+        return {}
+    torch.cuda.synchronize()
+    return {k: [a.elapsed_time(b) for a, b in v] for k, v in t.items()}
+
+
+class _timed:
+    __slots__ = ("key", "a")
+
+    def __init__(self, key):
+        self.key = key if (_timing is not None and (_timing_filter is None or _timing_filter == key)) else None
+
+    def __enter__(self):
+        if self.key is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.key is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            _timing.setdefault(self.key, []).append((self.a, b))
+        return False
+
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
@@ -62,8 +104,9 @@ def conv5x5_fwd(x, w, bias, stride):
         _req(bias, "bias")
     OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
     y = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
-    check(lib.vg_conv5x5_fwd(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W, Cout, stride,
-                             _stream()), "vg_conv5x5_fwd")
+    with _timed(("conv_fwd", B, Cin, H, W, Cout, stride)):
+        check(lib.vg_conv5x5_fwd(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W, Cout,
+                                 stride, _stream()), "vg_conv5x5_fwd")
     return y
 
 
@@ -78,8 +121,9 @@ def convT5x5_fwd(x, w, bias, stride):
     if bias is not None:
         _req(bias, "bias")
     y = torch.empty((B, Cout, H * stride, W * stride), dtype=torch.float32, device=x.device)
-    check(lib.vg_convT5x5_fwd(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W, Cout, stride,
-                              _stream()), "vg_convT5x5_fwd")
+    with _timed(("convT_fwd", B, Cin, H, W, Cout, stride)):
+        check(lib.vg_convT5x5_fwd(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W, Cout,
+                                  stride, _stream()), "vg_convT5x5_fwd")
     return y
 
 
@@ -95,8 +139,9 @@ def conv5x5_wgrad(x, gy, stride, out=None):
     dw = out if out is not None else torch.empty((Cout, Cin, 5, 5), dtype=torch.float32, device=x.device)
     need = lib.vg_conv5x5_wgrad_workspace_bytes(B, Cin, H, W, Cout, stride)
     ws = workspace(need, x.device)
-    check(lib.vg_conv5x5_wgrad(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout, stride,
-                               ws.data_ptr(), ws.numel(), _stream()), "vg_conv5x5_wgrad")
+    with _timed(("conv_wgrad", B, Cin, H, W, Cout, stride)):
+        check(lib.vg_conv5x5_wgrad(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout, stride,
+                                   ws.data_ptr(), ws.numel(), _stream()), "vg_conv5x5_wgrad")
     return dw
 
 
@@ -163,6 +208,16 @@ def act_bwd(gy, y, kind):
     return gx
 
 
+def scale_by_scalar(g, s):
+    """g * s[0] with s a 0-dim device tensor (no host read)."""
+    lib = _lib.load()
+    _req(g, "g"), _req(s, "s")
+    out = torch.empty_like(g)
+    check(lib.vg_scale_by_scalar(g.data_ptr(), s.data_ptr(), out.data_ptr(), g.numel(), _stream()),
+          "vg_scale_by_scalar")
+    return out
+
+
 # ---------------------------------------------------------------------- losses
 def reparam_kl_fwd(mu, logvar, eps, beta, want_rows=False):
     lib = _lib.load()
@@ -177,10 +232,15 @@ def reparam_kl_fwd(mu, logvar, eps, beta, want_rows=False):
 
 
 def reparam_kl_bwd(gz, mu, logvar, eps, gkl, beta):
+    """gz: tensor or None; gkl: 0-dim device tensor (upstream grad of the KL scalar) or None."""
     lib = _lib.load()
     B, D = mu.shape
     gmu, glv = torch.empty_like(mu), torch.empty_like(mu)
-    check(lib.vg_reparam_kl_bwd(_ptr(gz), mu.data_ptr(), logvar.data_ptr(), eps.data_ptr(), float(gkl), float(beta),
+    if gz is not None:
+        _req(gz, "gz")
+    if gkl is not None:
+        _req(gkl, "gkl")
+    check(lib.vg_reparam_kl_bwd(_ptr(gz), mu.data_ptr(), logvar.data_ptr(), eps.data_ptr(), _ptr(gkl), float(beta),
                                 gmu.data_ptr(), glv.data_ptr(), B, D, _stream()), "vg_reparam_kl_bwd")
     return gmu, glv
 

@@ -1,0 +1,290 @@
+"""Training-step drivers: the counterparts of the reference's ``train(epoch)`` loop
+bodies, one process per GPU.
+
+  BetaVAEGANTrainer.step  <->  experiments/new_betavaegan.py:87-193
+  VAETrainer.step         <->  experiments/new_vae.py:53-59
+  GANTrainer.step         <->  experiments/new_gan.py:66-141
+
+Observable results follow the reference (three optimizer steps per iteration, all of
+EG moves in both EG phases, BatchNorm running statistics updated by every forward
+in the reference's order, train-mode BN everywhere).  Provably dead work is
+skipped:
+  * the separate ``backward()`` calls of a phase are one backward of the summed loss;
+  * in the decoder phase the discriminator only relays gradients: its parameters are
+    frozen (no weight gradients) and ``sim_real`` is computed without a graph.
+No host synchronisation happens inside ``step``; loss scalars stay on the device.
+
+Data parallelism: every rank holds a replica and a shard of the batch; BatchNorm
+statistics are replica-local (as under the reference's nn.DataParallel); before each
+optimizer step the gradients, laid out in one flat fp32 buffer per network, are
+summed with a single RCCL all-reduce (SUM, not mean: sum-reduced losses use local
+sums, BCE is divided by the *global* batch), which reproduces the global-batch
+gradient.
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import optim
+
+from . import functional as F
+from .model import VAE, Discriminator_celeba, Generator_celeba, weights_init
+
+
+@dataclass
+class ModelOpt:
+    """The fields of the reference's argparse namespace the models read
+    (utils/envsetter.py:41-42,45)."""
+    input_channels: int = 3
+    n_hidden: int = 128
+    n_z: List[int] = field(default_factory=lambda: [256, 8, 8])
+
+
+class FlatGrads:
+    """All gradients of a network as views into one contiguous fp32 buffer, so a phase's
+    gradient exchange is a single large all-reduce over xGMI."""
+
+    def __init__(self, params):
+        self.params = [p for p in params]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        self.views = []
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def zero_and_attach(self):
+        self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def all_reduce(self, group=None):
+        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+
+
+def _make_adam(params, lr, fused):
+    return optim.Adam(params, lr=lr, fused=fused) if fused else optim.Adam(params, lr=lr)
+
+
+def _dist_world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class BetaVAEGANTrainer:
+    """One replica of the beta-VAE-GAN (new_betavaegan.py:36-53 construction recipe)."""
+
+    def __init__(self, device="cuda", seed=999, beta=25.0, lr=1e-3, opt: Optional[ModelOpt] = None,
+                 data_parallel: Optional[bool] = None, fused_adam: bool = True):
+        self.opt = opt or ModelOpt()
+        self.device = torch.device(device)
+        self.beta = float(beta)
+        torch.manual_seed(seed)                       # new_betavaegan.py:36
+        net_eg = VAE(self.opt)                        # :41  (constructed on CPU: same RNG stream
+        net_d = Discriminator_celeba(self.opt)        # :43   as the reference => identical weights)
+        net_eg.apply(weights_init)                    # :46
+        net_d.apply(weights_init)                     # :47
+        self.netEG = net_eg.to(self.device)
+        self.netD = net_d.to(self.device)
+        fused = fused_adam and self.device.type == "cuda"
+        self.optimizerEG = _make_adam(self.netEG.parameters(), lr, fused)   # :49 (hard-coded 1e-3 there)
+        self.optimizerD = _make_adam(self.netD.parameters(), lr, fused)     # :50
+        self.world = _dist_world()
+        self.dp = (self.world > 1) if data_parallel is None else data_parallel
+        self.flat_eg = FlatGrads(self.netEG.parameters()) if self.dp else None
+        self.flat_d = FlatGrads(self.netD.parameters()) if self.dp else None
+        self.netEG.train()
+        self.netD.train()
+        self.iteration = 0
+
+    # -- gradient plumbing ------------------------------------------------------
+    def _zero(self, net, flat):
+        if flat is not None:
+            flat.zero_and_attach()
+        else:
+            net.zero_grad(set_to_none=True)
+
+    def _exchange(self, flat):
+        if flat is not None and self.world > 1:
+            flat.all_reduce()
+
+    def _set_d_frozen(self, frozen):
+        for p in self.netD.parameters():
+            p.requires_grad_(not frozen)
+
+    # -- one iteration ------------------------------------------------------------
+    def step(self, data, noise=None, eps2=None, eps3=None, real_label=0.9, fake_label=0.1,
+             global_batch: Optional[int] = None, grad_hook=None) -> Dict[str, torch.Tensor]:
+        """data (B,3,64,64) in [-1,1]; noise / eps2 / eps3 (B, n_hidden) ~ N(0,1) are drawn on
+        the device when omitted (new_betavaegan.py:111, model.py:534).  Labels are the
+        per-iteration scalars of :89-90.  Returns device scalars (no sync).
+        ``grad_hook(phase, net)`` (tests) is called right before each optimizer step."""
+        netEG, netD = self.netEG, self.netD
+        B = data.size(0)
+        nh = self.opt.n_hidden
+        if noise is None:
+            noise = torch.randn(B, nh, device=data.device)
+        if eps2 is None:
+            eps2 = torch.randn(B, nh, device=data.device)
+        if eps3 is None:
+            eps3 = torch.randn(B, nh, device=data.device)
+        gb = global_batch if global_batch is not None else B * self.world
+        out = {}
+
+        # ---- phase 1: discriminator (:95-123)
+        self._zero(netD, self.flat_d)
+        p_real, _ = netD(data)
+        err_real = F.bce_loss(p_real, real_label, gb)
+        fake = netEG.decode(noise)                           # graph kept for phase 2 (:113)
+        p_fake, _ = netD(fake.detach())
+        err_fake = F.bce_loss(p_fake, fake_label, gb)
+        torch.autograd.backward([err_real, err_fake])
+        self._exchange(self.flat_d)
+        if grad_hook:
+            grad_hook("D", netD)
+        self.optimizerD.step()
+        out["errD_real"], out["errD_fake"] = err_real.detach(), err_fake.detach()
+        out["D_x_sum"] = p_real.detach().sum()
+
+        # ---- phase 2: "decoder" -- every EG parameter moves (:127-164)
+        self._zero(netEG, self.flat_eg)
+        self._set_d_frozen(True)
+        with torch.no_grad():
+            _, sim_real = netD(data)                         # D fwd #3: BN statistics still update
+        recon, mu, logvar = netEG(data, eps2)
+        p_fake2, _ = netD(fake)
+        p_rec, sim_rec = netD(recon)
+        err_g_fake = F.bce_loss(p_fake2, real_label, gb)
+        err_g_rec = F.bce_loss(p_rec, real_label, gb)
+        sim = F.sim_loss(sim_rec, sim_real)
+        mse2 = F.reconstruction_loss(recon, data)
+        torch.autograd.backward([err_g_fake, err_g_rec, sim, mse2])
+        self._set_d_frozen(False)
+        self._exchange(self.flat_eg)
+        if grad_hook:
+            grad_hook("EG2", netEG)
+        self.optimizerEG.step()
+        out.update(errG_fake=err_g_fake.detach(), errG_recon=err_g_rec.detach(), sim=sim.detach(),
+                   mse_dec=mse2.detach())
+
+        # ---- phase 3: "encoder" -- again every EG parameter moves (:167-193)
+        self._zero(netEG, self.flat_eg)
+        recon, mu, logvar, kld = netEG.forward_with_kl(data, eps3, self.beta)
+        mse3 = F.reconstruction_loss(recon, data)
+        torch.autograd.backward([kld, mse3])
+        self._exchange(self.flat_eg)
+        if grad_hook:
+            grad_hook("EG3", netEG)
+        self.optimizerEG.step()
+        out.update(kld=kld.detach(), mse_enc=mse3.detach())
+        self.iteration += 1
+        return out
+
+    # -- checkpoint (new_betavaegan.py:203-209, 222-228) --------------------------------
+    def checkpoint(self, epoch):
+        """The reference's dict.  ``discriminator_model`` keys carry the ``module.`` prefix
+        because the reference saves the DataParallel-wrapped netD (:44, :225)."""
+        return {
+            "epoch": epoch,
+            "encoder_decoder_model": self.netEG.state_dict(),
+            "discriminator_model": {"module." + k: v for k, v in self.netD.state_dict().items()},
+            "encoder_decoder_optimizer": self.optimizerEG.state_dict(),
+            "discriminator_optimizer": self.optimizerD.state_dict(),
+        }
+
+    def save(self, path, epoch):
+        torch.save(self.checkpoint(epoch), path)
+
+    def load(self, path_or_dict):
+        ck = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location=self.device)
+        self.netEG.load_state_dict(ck["encoder_decoder_model"])
+        d_sd = ck["discriminator_model"]
+        if all(k.startswith("module.") for k in d_sd):       # both layouts accepted
+            d_sd = {k[len("module."):]: v for k, v in d_sd.items()}
+        self.netD.load_state_dict(d_sd)
+        self.optimizerEG.load_state_dict(ck["encoder_decoder_optimizer"])
+        self.optimizerD.load_state_dict(ck["discriminator_optimizer"])
+        return ck["epoch"]
+
+
+class VAETrainer:
+    """new_vae.py:33-37 construction, :39-48 loss, :53-59 step."""
+
+    def __init__(self, device="cuda", seed=999, beta=1.0, lr=3e-3, opt: Optional[ModelOpt] = None,
+                 fused_adam: bool = True):
+        self.opt = opt or ModelOpt()
+        self.device = torch.device(device)
+        self.beta = float(beta)
+        torch.manual_seed(seed)
+        m = VAE(self.opt)
+        m.apply(weights_init)
+        self.model = m.to(self.device)
+        self.optimizer = _make_adam(self.model.parameters(), lr, fused_adam and self.device.type == "cuda")
+        self.world = _dist_world()
+        self.flat = FlatGrads(self.model.parameters()) if self.world > 1 else None
+        self.model.train()
+
+    def step(self, data, eps=None):
+        if self.flat is not None:
+            self.flat.zero_and_attach()
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+        recon, mu, logvar, kld = self.model.forward_with_kl(data, eps, self.beta)
+        mse = F.reconstruction_loss(recon, data)
+        torch.autograd.backward([mse, kld])
+        if self.flat is not None:
+            self.flat.all_reduce()
+        self.optimizer.step()
+        return dict(mse=mse.detach(), kld=kld.detach())
+
+    def checkpoint(self, epoch):
+        return {"epoch": epoch, "VAE_model": self.model.state_dict(), "optimizer": self.optimizer.state_dict()}
+
+
+class GANTrainer:
+    """new_gan.py:47-61 construction, :66-141 step."""
+
+    def __init__(self, device="cuda", seed=999, lr=3e-3, opt: Optional[ModelOpt] = None, fused_adam: bool = True):
+        self.opt = opt or ModelOpt()
+        self.device = torch.device(device)
+        torch.manual_seed(seed)
+        g = Generator_celeba(self.opt)
+        d = Discriminator_celeba(self.opt)
+        g.apply(weights_init)
+        d.apply(weights_init)
+        self.netG, self.netD = g.to(self.device), d.to(self.device)
+        fused = fused_adam and self.device.type == "cuda"
+        self.optimizerG = _make_adam(self.netG.parameters(), lr, fused)
+        self.optimizerD = _make_adam(self.netD.parameters(), lr, fused)
+        self.netG.train()
+        self.netD.train()
+
+    def step(self, data, noise=None, real_label=0.9, fake_label=0.1):
+        B = data.size(0)
+        if noise is None:
+            noise = torch.randn(B, self.opt.n_hidden, device=data.device)
+        self.netD.zero_grad(set_to_none=True)
+        p_real, _ = self.netD(data)
+        err_real = F.bce_loss(p_real, real_label)
+        fake = self.netG(noise)
+        p_fake, _ = self.netD(fake.detach())
+        err_fake = F.bce_loss(p_fake, fake_label)
+        torch.autograd.backward([err_real, err_fake])
+        self.optimizerD.step()
+        self.netG.zero_grad(set_to_none=True)
+        for p in self.netD.parameters():
+            p.requires_grad_(False)
+        p_fake2, _ = self.netD(fake)
+        err_g = F.bce_loss(p_fake2, real_label)
+        err_g.backward()
+        for p in self.netD.parameters():
+            p.requires_grad_(True)
+        self.optimizerG.step()
+        return dict(errD_real=err_real.detach(), errD_fake=err_fake.detach(), errG=err_g.detach(),
+                    D_x_sum=p_real.detach().sum())
+
+    def checkpoint(self, epoch):
+        return {"epoch": epoch, "netG": self.netG.state_dict(), "netD": self.netD.state_dict(),
+                "G_trainer": self.optimizerG.state_dict(), "D_trainer": self.optimizerD.state_dict()}

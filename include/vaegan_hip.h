@@ -108,9 +108,15 @@ int vg_act_bwd(const float* gy, const float* y, float* gx, size_t n, int act_kin
 int vg_reparam_kl_fwd(const float* mu, const float* logvar, const float* eps, float* z, float* kl,
                       float* kl_rows, int B, int D, float beta, void* stream);
 /* gmu = gz + gkl*beta*mu ; glogvar = gz*eps*0.5*exp(logvar/2) + gkl*beta*0.5*(exp(logvar)-1).
- * gz may be NULL (treated as 0). */
+ * gz (tensor) and gkl (DEVICE scalar, the upstream gradient of kl[0]) may each be
+ * NULL (treated as 0). */
 int vg_reparam_kl_bwd(const float* gz, const float* mu, const float* logvar, const float* eps,
-                      float gkl, float beta, float* gmu, float* glogvar, int B, int D, void* stream);
+                      const float* gkl, float beta, float* gmu, float* glogvar, int B, int D, void* stream);
+
+/* out[i] = g[i] * s[0] with s a DEVICE scalar: applies the upstream gradient of a
+ * loss scalar to a gradient precomputed by the fused loss kernels, without a
+ * host read of s (out may alias g). */
+int vg_scale_by_scalar(const float* g, const float* s, float* out, size_t n, void* stream);
 
 /* loss[0] = scale * sum((a-b)^2);  ga = gscale * 2*scale*(a-b)  (ga may be NULL).
  * scale=0.5: Dis_l / SIM (new_betavaegan.py:67-69); scale=1: pixel MSE (:71-75). */

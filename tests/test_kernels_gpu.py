@@ -82,7 +82,7 @@ def test_loss_kats(H, kats):
     assert_close(z, torch.from_numpy(kats["rkl/z"]), 2e-6, "z")
     assert abs(float(kl) - float(kats["rkl/kl"])) <= 2e-6 * abs(float(kats["rkl/kl"]))
     assert abs(float(rows.sum()) * 25.0 - float(kats["rkl/kl"])) <= 1e-5 * abs(float(kats["rkl/kl"]))
-    gmu, glv = H.reparam_kl_bwd(gz, mu, lv, eps, 1.0, 25.0)
+    gmu, glv = H.reparam_kl_bwd(gz, mu, lv, eps, torch.ones((), device='cuda'), 25.0)
     assert_close(gmu, torch.from_numpy(kats["rkl/gmu"]), 2e-6, "gmu")
     assert_close(glv, torch.from_numpy(kats["rkl/glv"]), 2e-6, "glv")
     for tag, scale in (("disl", 0.5), ("mse", 1.0)):
