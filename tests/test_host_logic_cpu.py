@@ -1,0 +1,118 @@
+"""CPU: host-side logic of the product package that needs no device -- module zoo layout /
+seed recipe / checkpoint format against the oracle, and the data-parallel gradient exchange
+(flat buckets + all-reduce SUM) with 2 gloo ranks against an in-process 2-replica emulation."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from oracle import steps as osteps
+
+
+def test_module_zoo_matches_reference_layout_and_seed_recipe():
+    from disentangle_mlp_amd import model as M
+    from disentangle_mlp_amd.trainer import ModelOpt
+    torch.manual_seed(999)
+    a, d = M.VAE(ModelOpt()), M.Discriminator_celeba(ModelOpt())
+    a.apply(M.weights_init), d.apply(M.weights_init)
+    b, e, _, _ = osteps.build_nets()
+    for x, y in ((a, b), (d, e)):
+        sx, sy = x.state_dict(), y.state_dict()
+        assert list(sx) == list(sy)
+        assert all(torch.equal(sx[k], sy[k]) for k in sx)       # bit-identical initial weights
+    y.load_state_dict(sx)
+    x.load_state_dict(sy)
+    g1, g2 = M.Generator_celeba(ModelOpt()), oracle.Generator_celeba(oracle.OracleOpt())
+    e1, e2 = M.Encoder_celeba(ModelOpt()), oracle.Encoder_celeba(oracle.OracleOpt())
+    assert list(g1.state_dict()) == list(g2.state_dict())
+    assert list(e1.state_dict()) == list(e2.state_dict())
+
+
+def test_num_batches_tracked_is_flushed_into_state_dict():
+    from disentangle_mlp_amd.model import HipBatchNorm2d
+    bn = HipBatchNorm2d(4)
+    bn._nbt_pending = 3
+    assert int(bn.state_dict()["num_batches_tracked"]) == 3
+    assert bn._nbt_pending == 0
+
+
+def test_transposed_conv_rejects_foreign_output_size():
+    from disentangle_mlp_amd.model import HipConvTranspose2d
+    m = HipConvTranspose2d(4, 4, 2)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 4, 8, 8), output_size=(1, 4, 15, 15))   # the reference's Generator at n_z!=8x8
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _replica_grads(rank, world, batch, phase_out):
+    """Oracle phase-1 (discriminator) gradients of one replica on its shard, BCE divided by
+    the global batch."""
+    eg, d, oeg, od = osteps.build_nets()
+    b = osteps.synthetic_batch(batch)
+    lo, hi = rank * batch // world, (rank + 1) * batch // world
+    sh = {k: v[lo:hi] for k, v in b.items()}
+    grads = {}
+
+    class Stop(Exception):
+        pass
+
+    def hook(ph, net):
+        grads[ph] = [p.grad.detach().clone() for p in net.parameters()]
+        raise Stop
+    try:
+        osteps.betavaegan_step(eg, d, oeg, od, sh["data"], sh["noise"], sh["eps2"], sh["eps3"],
+                               bce_divisor=batch, grad_hook=hook)
+    except Stop:
+        pass
+    return d, grads["D"]
+
+
+def _dp_worker(rank, world, port, batch, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from disentangle_mlp_amd.trainer import FlatGrads
+    d, g = _replica_grads(rank, world, batch, None)
+    flat = FlatGrads(d.parameters())
+    flat.zero_and_attach()
+    for p, gi in zip(d.parameters(), g):
+        p.grad.add_(gi)                      # what autograd's accumulation does in the trainer
+    flat.all_reduce()
+    if rank == 0:
+        q.put(flat.flat.clone())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_equals_two_replica_emulation():
+    world, batch = 2, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    torch.set_num_threads(2)
+    want = None
+    for r in range(world):
+        _, g = _replica_grads(r, world, batch, None)
+        flat = torch.cat([t.flatten() for t in g])
+        want = flat if want is None else want + flat
+    assert got.shape == want.shape == (36122945,)
+    err = float((got - want).norm() / want.norm())
+    assert err <= 1e-6, err

@@ -5,7 +5,7 @@ import math
 import pytest
 import torch
 
-from conftest import load_json, BN_SHADOWED
+from conftest import load_json, BN_SHADOWED, LOSS_TOL, GRADNORM_TOL, gap, check_state
 import oracle
 from oracle import steps
 
@@ -58,34 +58,28 @@ def test_kat0(tag, dtype, rel):
     assert int(eg.state_dict()["features.1.num_batches_tracked"]) == g["bn_nbt"]
 
 
-def _check_state(state, gold, skip, rel, abs_):
-    for k, v in state.items():
-        if k in skip:
-            continue
-        s, a = float(v.double().sum()), float(v.double().abs().sum())
-        assert close(a, gold[k][1], rel, abs_), (k, a, gold[k][1])
-        assert close(s, gold[k][0], rel, abs_ + rel * a), (k, s, gold[k][0])
-
-
 @pytest.mark.parametrize("batch", [4, 16])
 def test_betavaegan_step_fp32(batch):
-    g = load_json(f"step_b{batch}.json")["fp32"]
+    gg = load_json(f"step_b{batch}.json")
+    g, g64 = gg["fp32"], gg["fp64"]
     eg, d, oeg, od = steps.build_nets()
     b = steps.synthetic_batch(batch)
     grads = {}
     losses = steps.betavaegan_step(eg, d, oeg, od, b["data"], b["noise"], b["eps2"], b["eps3"], beta=25.0,
                                    grad_hook=lambda ph, net: grads.__setitem__(
                                        ph, {k: float(p.grad.double().norm()) for k, p in net.named_parameters()}))
+    # tolerances: conftest.LOSS_TOL / GRADNORM_TOL (phase 1 tight; after the first Adam step the
+    # iteration is chaotic even between two thread counts of this very oracle)
     for k, v in g["losses"].items():
-        assert close(losses[k], v, 1e-4), (k, losses[k], v)
+        assert close(losses[k], v, max(LOSS_TOL[k], 5 * gap(v, g64["losses"][k]))), (k, losses[k], v)
     for ph, key in (("D", "d"), ("EG2", "eg"), ("EG3", "eg")):
         for k, v in g["grad_norms"][ph].items():
             if k in BN_SHADOWED[key]:
                 continue
-            assert close(grads[ph][k], v, 1e-3, 1e-6), (ph, k, grads[ph][k], v)
-    # one Adam step moves every weight by ~lr; checksums of |w| move by <= lr*numel
-    _check_state(eg.state_dict(), g["eg_state"], BN_SHADOWED["eg"], 1e-4, 1e-4)
-    _check_state(d.state_dict(), g["d_state"], BN_SHADOWED["d"], 1e-4, 1e-4)
+            tol = max(GRADNORM_TOL[ph], 5 * gap(v, g64["grad_norms"][ph][k]))
+            assert close(grads[ph][k], v, tol, 1e-6), (ph, k, grads[ph][k], v)
+    check_state(eg.state_dict(), g["eg_state"], g64["eg_state"], BN_SHADOWED["eg"], 1e-3)
+    check_state(d.state_dict(), g["d_state"], g64["d_state"], BN_SHADOWED["d"], 1e-3)
     assert int(d.state_dict()["convs.1.num_batches_tracked"]) == 5
     assert int(eg.state_dict()["features.1.num_batches_tracked"]) == 2
     assert int(eg.state_dict()["act1.0.num_batches_tracked"]) == 3
@@ -101,7 +95,8 @@ def test_betavaegan_step_fp64_b4():
 
 
 def test_vae_step_b16():
-    g = load_json("vae_step_b16.json")["fp32"]
+    gg = load_json("vae_step_b16.json")
+    g, g64 = gg["fp32"], gg["fp64"]
     torch.manual_seed(999)
     m = oracle.VAE(oracle.OracleOpt())
     m.apply(oracle.weights_init)
@@ -110,11 +105,12 @@ def test_vae_step_b16():
     losses = steps.vae_step(m, o, b["data"], b["eps2"], beta=1.0)
     for k, v in g["losses"].items():
         assert close(losses[k], v, 1e-4)
-    _check_state(m.state_dict(), g["state"], BN_SHADOWED["eg"], 1e-4, 1e-4)
+    check_state(m.state_dict(), g["state"], g64["state"], BN_SHADOWED["eg"], 3e-3)
 
 
 def test_gan_step_b4():
-    g = load_json("gan_step_b4.json")["fp32"]
+    gg = load_json("gan_step_b4.json")
+    g, g64 = gg["fp32"], gg["fp64"]
     torch.manual_seed(999)
     gen = oracle.Generator_celeba(oracle.OracleOpt())
     d = oracle.Discriminator_celeba(oracle.OracleOpt())
@@ -125,9 +121,9 @@ def test_gan_step_b4():
     b = steps.synthetic_batch(4)
     losses = steps.gan_step(gen, d, og, od, b["data"], b["noise"])
     for k, v in g["losses"].items():
-        assert close(losses[k], v, 1e-4)
-    _check_state(gen.state_dict(), g["g_state"], BN_SHADOWED["g"], 1e-4, 1e-4)
-    _check_state(d.state_dict(), g["d_state"], BN_SHADOWED["d"], 1e-4, 1e-4)
+        assert close(losses[k], v, LOSS_TOL[k]), k
+    check_state(gen.state_dict(), g["g_state"], g64["g_state"], BN_SHADOWED["g"], 3e-3)
+    check_state(d.state_dict(), g["d_state"], g64["d_state"], BN_SHADOWED["d"], 3e-3)
 
 
 def test_encoder_celeba_returns_per_sample_kld():
