@@ -20,6 +20,8 @@ _P, _I, _F, _Z = c_void_p, c_int, c_float, c_size_t
 # name -> (restype, argtypes); mirrors include/vaegan_hip.h one to one
 SIGNATURES = {
     "vg_version": (_I, []),
+    "vg_debug_set_conv_tile": (_I, [_I, _I]),
+    "vg_debug_set_wgrad": (_I, [_I, _I]),
     "vg_conv5x5_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_convT5x5_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_conv5x5_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),

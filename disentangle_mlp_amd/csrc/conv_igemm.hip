@@ -30,10 +30,10 @@ namespace {
 
 enum { MODE_FWD = 0, MODE_TR = 1 };
 
-template <int MODE_, int S_, int NB_, int TH_, int TW_, int TN_, int WC_, int WP_, int CK_>
+template <int MODE_, int S_, int NB_, int TH_, int TW_, int TN_, int WC_, int WP_, int CK_, int MINW_ = 2, int PIPE_ = 0>
 struct Cfg {
   static constexpr int MODE = MODE_, S = S_, NB = NB_, TH = TH_, TW = TW_, TN = TN_, WC = WC_, WP = WP_,
-                       CK = CK_;
+                       CK = CK_, MINW = MINW_, PIPE = PIPE_;
   static constexpr int NT = 64 * WC * WP;
   static constexpr int TM = NB * TH * TW;
   static constexpr int FC = TN / 32 / WC;  // 32-row cout fragments per wave
@@ -46,7 +46,7 @@ struct Cfg {
   static constexpr int NQP = cdiv(NP, NT);
   static constexpr int RLMAX = CK * NTMAX * NTMAX;
   static constexpr int WSMAX = RLMAX | 1;
-  static constexpr int STAGE = NP + TN * WSMAX;
+  static constexpr int STAGE = NP + TN * WSMAX + 1;  // +1: dummy slot for masked-off stores
   static constexpr int NCLS = (MODE == MODE_FWD) ? 1 : S * S;
   static_assert(TN % (32 * WC) == 0 && TM % (32 * WP) == 0 && CK % 2 == 0, "tile shape");
   static_assert(RLMAX <= NT, "one filter row per pass at least");
@@ -118,33 +118,41 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
   const float* wsrc = A.w + (size_t)(n0 + w_sub) * w_row_stride + w_c * w_ch_stride + w_kh * 5 + w_kw;
 
   float preg[NQP], wreg[NQW];
+  // Branch-free staging: an out-of-range element loads from offset 0 (always mapped); it is
+  // replaced by 0 only when the registers are written to LDS (after the MFMAs of the current
+  // chunk), so the loads stay in flight under the compute loop.
   auto load_chunk = [&](int c0) {
 #pragma unroll
     for (int q = 0; q < NQP; ++q) {
       const int e = tid + q * NT;
       const int c = (e / (PWP * PH)) % CK;
       const bool ok = pofs[q] >= 0 && (c0 + c) < Cin;
-      preg[q] = ok ? xb[pofs[q] + c0 * HW] : 0.f;
+      preg[q] = xb[ok ? pofs[q] + c0 * HW : 0];
     }
-    const float* wp_ = wsrc + c0 * w_ch_stride;
+    const bool cok = wrow_ok && (c0 + w_c) < Cin;
+    const float* wp_ = cok ? wsrc + c0 * w_ch_stride : A.w;
+#pragma unroll
+    for (int q = 0; q < NQW; ++q) {
+      const int co_l = w_sub + q * RP;
+      const bool ok = cok && co_l < TN && (n0 + co_l) < Cout;
+      wreg[q] = wp_[ok ? (size_t)q * RP * w_row_stride : 0];
+    }
+  };
+  auto store_chunk = [&](float* st, int c0) {
+    constexpr int DUMMY = C::STAGE - 1;
+#pragma unroll
+    for (int q = 0; q < NQP; ++q) {
+      const int e = tid + q * NT;
+      const int c = (e / (PWP * PH)) % CK;
+      const bool ok = pofs[q] >= 0 && (c0 + c) < Cin;
+      st[(e < NP) ? e : DUMMY] = ok ? preg[q] : 0.f;
+    }
     const bool cok = wrow_ok && (c0 + w_c) < Cin;
 #pragma unroll
     for (int q = 0; q < NQW; ++q) {
       const int co_l = w_sub + q * RP;
       const bool ok = cok && co_l < TN && (n0 + co_l) < Cout;
-      wreg[q] = ok ? wp_[(size_t)q * RP * w_row_stride] : 0.f;
-    }
-  };
-  auto store_chunk = [&](float* st) {
-#pragma unroll
-    for (int q = 0; q < NQP; ++q) {
-      const int e = tid + q * NT;
-      if (e < NP) st[e] = preg[q];
-    }
-    float* wl = st + NP;
-#pragma unroll
-    for (int q = 0; q < NQW; ++q) {
-      if (wrow_ok && (w_sub + q * RP) < TN) wl[(w_sub + q * RP) * WS + w_r] = wreg[q];
+      st[(wrow_ok && co_l < TN) ? NP + co_l * WS + w_r : DUMMY] = ok ? wreg[q] : 0.f;
     }
   };
 
@@ -169,32 +177,52 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
 
   const int nchunks = (Cin + CK - 1) / CK;
   load_chunk(0);
-  store_chunk(smem);
+  store_chunk(smem, 0);
   __syncthreads();
 
   for (int ch = 0; ch < nchunks; ++ch) {
     const float* st = smem + (ch & 1) * C::STAGE;
     const bool more = (ch + 1) < nchunks;
     if (more) load_chunk((ch + 1) * CK);
+    // (cp, tap) steps, operands of step t+1 read from LDS before the MFMAs of step t issue
+    constexpr int NSTEP = (CK / 2) * NTAP;
+    float a_cur[FC], b_cur[FP], a_nxt[FC], b_nxt[FP];
+    auto read_step = [&](int stp, float* a, float* b) {
+      const int cp = stp / NTAP, t = stp % NTAP;
+      const int ro = (MODE == MODE_FWD) ? t / 5 : NTMAX - 1 - t / NTW;   // patch row / col offset of the tap
+      const int cof = (MODE == MODE_FWD) ? t % 5 : NTMAX - 1 - t % NTW;
 #pragma unroll
-    for (int cp = 0; cp < CK / 2; ++cp) {
+      for (int g = 0; g < FC; ++g) a[g] = st[base_w[g] + cp * 2 * NTAP + t];
 #pragma unroll
-      for (int t = 0; t < NTAP; ++t) {
-        // patch row/col offset of this tap relative to the tile pixel
-        const int ro = (MODE == MODE_FWD) ? t / 5 : NTMAX - 1 - t / NTW;
-        const int cof = (MODE == MODE_FWD) ? t % 5 : NTMAX - 1 - t % NTW;
-        float a[FC], b[FP];
+      for (int f = 0; f < FP; ++f) b[f] = st[base_p[f] + (2 * cp * PH + ro) * PWP + cof];
+    };
+    if constexpr (C::PIPE) {
+      read_step(0, a_cur, b_cur);
 #pragma unroll
-        for (int g = 0; g < FC; ++g) a[g] = st[base_w[g] + cp * 2 * NTAP + t];
-#pragma unroll
-        for (int f = 0; f < FP; ++f) b[f] = st[base_p[f] + (2 * cp * PH + ro) * PWP + cof];
+      for (int stp = 0; stp < NSTEP; ++stp) {
+        if (stp + 1 < NSTEP) read_step(stp + 1, a_nxt, b_nxt);
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this step's MFMAs
 #pragma unroll
         for (int g = 0; g < FC; ++g)
 #pragma unroll
-          for (int f = 0; f < FP; ++f) acc[g][f] = mfma32(a[g], b[f], acc[g][f]);
+          for (int f = 0; f < FP; ++f) acc[g][f] = mfma32(a_cur[g], b_cur[f], acc[g][f]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < FC; ++g) a_cur[g] = a_nxt[g];
+#pragma unroll
+        for (int f = 0; f < FP; ++f) b_cur[f] = b_nxt[f];
+      }
+    } else {
+#pragma unroll
+      for (int stp = 0; stp < NSTEP; ++stp) {
+        read_step(stp, a_cur, b_cur);
+#pragma unroll
+        for (int g = 0; g < FC; ++g)
+#pragma unroll
+          for (int f = 0; f < FP; ++f) acc[g][f] = mfma32(a_cur[g], b_cur[f], acc[g][f]);
       }
     }
-    if (more) store_chunk(smem + ((ch + 1) & 1) * C::STAGE);
+    if (more) store_chunk(smem + ((ch + 1) & 1) * C::STAGE, (ch + 1) * CK);
     __syncthreads();
   }
 
@@ -224,7 +252,7 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
 }
 
 template <class C>
-__global__ __launch_bounds__(C::NT, 2) void conv5x5_igemm_kernel(Args A) {
+__global__ __launch_bounds__(C::NT, C::MINW) void conv5x5_igemm_kernel(Args A) {
   __shared__ float smem[2 * C::STAGE];
   int bid = blockIdx.x;
   if constexpr (C::NCLS == 1) {
@@ -268,55 +296,94 @@ int launch(const float* x, const float* w, const float* bias, float* y, int B, i
   return 0;
 }
 
-//                       MODE     S NB TH TW  TN WC WP CK
-using F2_w32_n128 = Cfg<MODE_FWD, 2, 1, 4, 32, 128, 2, 2, 2>;
-using F2_w16_n128 = Cfg<MODE_FWD, 2, 1, 8, 16, 128, 2, 2, 2>;
-using F2_w8_n128 = Cfg<MODE_FWD, 2, 2, 8, 8, 128, 2, 2, 2>;
-using F2_w32_n64 = Cfg<MODE_FWD, 2, 1, 4, 32, 64, 2, 2, 2>;
-using F2_w16_n64 = Cfg<MODE_FWD, 2, 1, 8, 16, 64, 2, 2, 2>;
-using F2_w8_n64 = Cfg<MODE_FWD, 2, 2, 8, 8, 64, 2, 2, 2>;
-using F2_w32_n32 = Cfg<MODE_FWD, 2, 1, 4, 32, 32, 1, 4, 2>;
-using F2_w8_n32 = Cfg<MODE_FWD, 2, 2, 8, 8, 32, 1, 4, 2>;
-using F1_w32_n128 = Cfg<MODE_FWD, 1, 1, 4, 32, 128, 2, 2, 2>;
-using F1_w32_n32 = Cfg<MODE_FWD, 1, 1, 4, 32, 32, 1, 4, 2>;
-using F1_w8_n32 = Cfg<MODE_FWD, 1, 2, 8, 8, 32, 1, 4, 2>;
+// ---- tile variants ------------------------------------------------------------------
+// Geometry by tile-space width: W32 -> rows of 32 pixels, W16 -> 16, W8 -> 8x8 images.
+//   variant 0: 128 px x 128 cout, CK 2 (fwd) / 4 (tr)     variant 3: 128 px x 64 cout, CK 2 / 4
+//   variant 1: 128 px x 64 cout, pinned LDS prefetch      variant 4: 128 px x 64 cout, CK 4 / 8
+//   variant 2: 64 px x 64 cout                            variant 5: 128 px x 128 cout, pinned prefetch
+//   variant 6: 128 px x 32 cout (thin outputs), 4 waves along the pixels
+template <int MODE, int S, int WIDTH, int VAR>
+struct Pick;
+#define VG_PICK(WIDTH, VAR, NB, TH, TW, TN, WC, WP, CKF, CKT, PIPE)                                         \
+  template <int MODE, int S>                                                                              \
+  struct Pick<MODE, S, WIDTH, VAR> {                                                                      \
+    using type = Cfg<MODE, S, NB, TH, TW, TN, WC, WP, ((MODE == MODE_FWD || S == 1) ? CKF : CKT), 2, PIPE>; \
+  };
+//       W  V NB TH TW   TN WC WP CKF CKT PIPE
+VG_PICK(32, 0, 1, 4, 32, 128, 2, 2, 2, 4, 0)
+VG_PICK(16, 0, 1, 8, 16, 128, 2, 2, 2, 4, 0)
+VG_PICK(8, 0, 2, 8, 8, 128, 2, 2, 2, 4, 0)
+VG_PICK(32, 1, 1, 4, 32, 64, 2, 2, 2, 4, 1)
+VG_PICK(16, 1, 1, 8, 16, 64, 2, 2, 2, 4, 1)
+VG_PICK(8, 1, 2, 8, 8, 64, 2, 2, 2, 4, 1)
+VG_PICK(32, 2, 1, 2, 32, 64, 2, 2, 2, 4, 0)
+VG_PICK(16, 2, 1, 4, 16, 64, 2, 2, 2, 4, 0)
+VG_PICK(8, 2, 1, 8, 8, 64, 2, 2, 2, 4, 0)
+VG_PICK(32, 3, 1, 4, 32, 64, 2, 2, 2, 4, 0)
+VG_PICK(16, 3, 1, 8, 16, 64, 2, 2, 2, 4, 0)
+VG_PICK(8, 3, 2, 8, 8, 64, 2, 2, 2, 4, 0)
+VG_PICK(32, 4, 1, 4, 32, 64, 2, 2, 4, 8, 0)
+VG_PICK(16, 4, 1, 8, 16, 64, 2, 2, 4, 8, 0)
+VG_PICK(8, 4, 2, 8, 8, 64, 2, 2, 4, 8, 0)
+VG_PICK(32, 5, 1, 4, 32, 128, 2, 2, 2, 4, 1)
+VG_PICK(16, 5, 1, 8, 16, 128, 2, 2, 2, 4, 1)
+VG_PICK(8, 5, 2, 8, 8, 128, 2, 2, 2, 4, 1)
+VG_PICK(32, 6, 1, 4, 32, 32, 1, 4, 2, 4, 0)
+VG_PICK(16, 6, 1, 8, 16, 32, 1, 4, 2, 4, 0)
+VG_PICK(8, 6, 2, 8, 8, 32, 1, 4, 2, 4, 0)
+#undef VG_PICK
+constexpr int NVAR = 7;
 
-using T2_w32_n128 = Cfg<MODE_TR, 2, 1, 4, 32, 128, 2, 2, 4>;
-using T2_w16_n128 = Cfg<MODE_TR, 2, 1, 8, 16, 128, 2, 2, 4>;
-using T2_w8_n128 = Cfg<MODE_TR, 2, 2, 8, 8, 128, 2, 2, 4>;
-using T2_w16_n64 = Cfg<MODE_TR, 2, 1, 8, 16, 64, 2, 2, 4>;
-using T2_w8_n64 = Cfg<MODE_TR, 2, 2, 8, 8, 64, 2, 2, 4>;
-using T2_w32_n32 = Cfg<MODE_TR, 2, 1, 4, 32, 32, 1, 4, 4>;
-using T2_w8_n32 = Cfg<MODE_TR, 2, 2, 8, 8, 32, 1, 4, 4>;
-using T1_w32_n128 = Cfg<MODE_TR, 1, 1, 4, 32, 128, 2, 2, 2>;
-using T1_w32_n32 = Cfg<MODE_TR, 1, 1, 4, 32, 32, 1, 4, 2>;
-using T1_w8_n32 = Cfg<MODE_TR, 1, 2, 8, 8, 32, 1, 4, 2>;
+int g_tile_override[2] = {-1, -1};  // diagnostics only (vg_debug_set_conv_tile)
+
+template <int MODE, int S, int WIDTH>
+int launch_var(int var, const float* x, const float* w, const float* bias, float* y, int B, int Cin, int XH,
+               int XW, int Cout, hipStream_t st) {
+  switch (var) {
+    case 0: return launch<typename Pick<MODE, S, WIDTH, 0>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    case 1: return launch<typename Pick<MODE, S, WIDTH, 1>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    case 2: return launch<typename Pick<MODE, S, WIDTH, 2>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    case 3: return launch<typename Pick<MODE, S, WIDTH, 3>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    case 4: return launch<typename Pick<MODE, S, WIDTH, 4>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    case 5: return launch<typename Pick<MODE, S, WIDTH, 5>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    default: return launch<typename Pick<MODE, S, WIDTH, 6>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+  }
+}
+
+// Tile choice: widest pixel row the tile space supports; cout tile to fit Cout; smaller tiles
+// when the big ones would leave CUs idle (256 CUs x 2 resident workgroups).
+template <int MODE, int S>
+int dispatch(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int XH, int XW,
+             int Cout, hipStream_t st) {
+  const int tsw = (MODE == MODE_FWD) ? (XW - 1) / S + 1 : XW;
+  const int tsh = (MODE == MODE_FWD) ? (XH - 1) / S + 1 : XH;
+  const int width = tsw >= 32 ? 32 : (tsw >= 16 ? 16 : 8);
+  // Measured on MI355X at B=128 (scripts/tune_conv.py): 128 px x 64 cout with the shallow K chunk
+  // wins or ties on every heavy layer (4 resident workgroups per CU hide the staging).
+  const int var = (Cout <= 32) ? 6 : 3;
+  (void)tsh;
+  const int ov = g_tile_override[MODE];
+  const int use = (ov >= 0 && ov < NVAR) ? ov : var;
+  if (width == 32) return launch_var<MODE, S, 32>(use, x, w, bias, y, B, Cin, XH, XW, Cout, st);
+  if (width == 16) return launch_var<MODE, S, 16>(use, x, w, bias, y, B, Cin, XH, XW, Cout, st);
+  return launch_var<MODE, S, 8>(use, x, w, bias, y, B, Cin, XH, XW, Cout, st);
+}
 
 }  // namespace
+
+extern "C" int vg_debug_set_conv_tile(int mode, int variant) {
+  if (mode < 0 || mode > 1) return VG_ERR_BAD_ARG;
+  g_tile_override[mode] = variant;
+  return 0;
+}
 
 extern "C" int vg_conv5x5_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin,
                               int H, int W, int Cout, int stride, void* stream) {
   if (!x || !w || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return VG_ERR_BAD_ARG;
   if (stride != 1 && stride != 2) return VG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
-  const int OW = (W - 1) / stride + 1;
-  if (stride == 2) {
-    if (Cout > 64) {
-      if (OW >= 32) return launch<F2_w32_n128>(x, w, bias, y, B, Cin, H, W, Cout, st);
-      if (OW >= 16) return launch<F2_w16_n128>(x, w, bias, y, B, Cin, H, W, Cout, st);
-      return launch<F2_w8_n128>(x, w, bias, y, B, Cin, H, W, Cout, st);
-    }
-    if (Cout > 32) {
-      if (OW >= 32) return launch<F2_w32_n64>(x, w, bias, y, B, Cin, H, W, Cout, st);
-      if (OW >= 16) return launch<F2_w16_n64>(x, w, bias, y, B, Cin, H, W, Cout, st);
-      return launch<F2_w8_n64>(x, w, bias, y, B, Cin, H, W, Cout, st);
-    }
-    if (OW >= 32) return launch<F2_w32_n32>(x, w, bias, y, B, Cin, H, W, Cout, st);
-    return launch<F2_w8_n32>(x, w, bias, y, B, Cin, H, W, Cout, st);
-  }
-  if (Cout > 32) return launch<F1_w32_n128>(x, w, bias, y, B, Cin, H, W, Cout, st);
-  if (OW >= 32) return launch<F1_w32_n32>(x, w, bias, y, B, Cin, H, W, Cout, st);
-  return launch<F1_w8_n32>(x, w, bias, y, B, Cin, H, W, Cout, st);
+  if (stride == 2) return dispatch<MODE_FWD, 2>(x, w, bias, y, B, Cin, H, W, Cout, st);
+  return dispatch<MODE_FWD, 1>(x, w, bias, y, B, Cin, H, W, Cout, st);
 }
 
 extern "C" int vg_convT5x5_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin,
@@ -324,20 +391,8 @@ extern "C" int vg_convT5x5_fwd(const float* x, const float* w, const float* bias
   if (!x || !w || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return VG_ERR_BAD_ARG;
   if (stride != 1 && stride != 2) return VG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (stride == 2) {  // tiles live in input space (H x W)
-    if (Cout > 64) {
-      if (W >= 32) return launch<T2_w32_n128>(x, w, bias, y, B, Cin, H, W, Cout, st);
-      if (W >= 16) return launch<T2_w16_n128>(x, w, bias, y, B, Cin, H, W, Cout, st);
-      return launch<T2_w8_n128>(x, w, bias, y, B, Cin, H, W, Cout, st);
-    }
-    if (Cout > 32) {
-      if (W >= 16) return launch<T2_w16_n64>(x, w, bias, y, B, Cin, H, W, Cout, st);
-      return launch<T2_w8_n64>(x, w, bias, y, B, Cin, H, W, Cout, st);
-    }
-    if (W >= 32) return launch<T2_w32_n32>(x, w, bias, y, B, Cin, H, W, Cout, st);
-    return launch<T2_w8_n32>(x, w, bias, y, B, Cin, H, W, Cout, st);
-  }
-  if (Cout > 32) return launch<T1_w32_n128>(x, w, bias, y, B, Cin, H, W, Cout, st);
-  if (W >= 32) return launch<T1_w32_n32>(x, w, bias, y, B, Cin, H, W, Cout, st);
-  return launch<T1_w8_n32>(x, w, bias, y, B, Cin, H, W, Cout, st);
+  if (stride == 2) return dispatch<MODE_TR, 2>(x, w, bias, y, B, Cin, H, W, Cout, st);
+  // <= 4 output channels: direct VALU kernel (an MFMA tile would be 3/32 full)
+  if (Cout <= 4 && g_tile_override[MODE_TR] < 0) return vg_internal_convT_s1_thin(x, w, bias, y, B, Cin, H, W, Cout, st);
+  return dispatch<MODE_TR, 1>(x, w, bias, y, B, Cin, H, W, Cout, st);
 }

@@ -1,0 +1,111 @@
+// Stride-1 5x5 transposed convolution with <= 4 output channels as a direct fp32 VALU
+// kernel for gfx950: the decoder's last layer (deconv4 32 -> 3, model.py:507) and the data
+// gradient of the discriminator's first layer (convs.0 3 <- 32, model.py:389).
+//
+// With 3 output channels an MFMA tile would be 3/32 full; the fp32 vector peak equals the
+// fp32 MFMA peak on this chip, so a register-tiled FMA kernel is the right tool:
+//   * workgroup = 16 x 64 output pixels of one image, thread = 4 consecutive pixels x COUT
+//     accumulators; the input patch [CK][20][68] is staged in LDS with coalesced row loads
+//     (zero-filled halo) and read back as aligned 16-byte vectors (8 floats feed 5 taps x
+//     4 pixels), the filter taps are wave-uniform and come through scalar loads.
+//   y[b][co][oh][ow] = bias[co] + sum_{ci,kh,kw} x[b][ci][oh+2-kh][ow+2-kw] * w[ci][co][kh][kw]
+#include "common.hpp"
+#include "vaegan_hip.h"
+
+namespace {
+
+constexpr int TH = 16, TW = 64, CK = 8, PH = TH + 4, PWS = TW + 4;  // PWS % 4 == 0: aligned b128 reads
+constexpr int NT = 256;
+
+template <int COUT>
+__global__ __launch_bounds__(NT) void convT_s1_thin_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           int Cin, int H, int W, int tiles_w, int tiles_hw) {
+  __shared__ __attribute__((aligned(16))) float patch[CK * PH * PWS];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / tiles_hw, sp = blockIdx.x % tiles_hw;
+  const int oh0 = (sp / tiles_w) * TH, ow0 = (sp % tiles_w) * TW;
+  const int r = tid / 16, cg = (tid % 16) * 4;   // this thread: row r, pixels cg..cg+3 of the tile
+  const int HW = H * W;
+  const float* xb = x + (size_t)b * Cin * HW;
+
+  float acc[COUT][4];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[co][p] = 0.f;
+
+  for (int c0 = 0; c0 < Cin; c0 += CK) {
+    // stage patch rows oh0-2 .. oh0+TH+1, cols ow0-2 .. ow0+TW+1 of CK channels
+    for (int e = tid; e < CK * PH * PWS; e += NT) {
+      const int col = e % PWS, t = e / PWS, pr = t % PH, c = t / PH;
+      const int ih = oh0 - 2 + pr, iw = ow0 - 2 + col;
+      const bool ok = (c0 + c) < Cin && ih >= 0 && ih < H && iw >= 0 && iw < W;
+      const float v = xb[ok ? (size_t)(c0 + c) * HW + ih * W + iw : 0];
+      patch[e] = ok ? v : 0.f;
+    }
+    __syncthreads();
+    const int cmax = min(CK, Cin - c0);
+    for (int c = 0; c < cmax; ++c) {
+      const float* wc = w + (size_t)(c0 + c) * COUT * 25;   // wave-uniform: scalar loads
+#pragma unroll
+      for (int kh = 0; kh < 5; ++kh) {
+        // output row r needs input row r+2-kh  ->  patch row r + 4 - kh
+        const float* row = patch + (c * PH + r + 4 - kh) * PWS + cg;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(row);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(row + 4);
+        const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int kw = 0; kw < 5; ++kw) {
+#pragma unroll
+          for (int co = 0; co < COUT; ++co) {
+            const float wv = wc[co * 25 + kh * 5 + kw];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[co][p] = fmaf(v[p + 4 - kw], wv, acc[co][p]);   // iw = ow+2-kw
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int oh = oh0 + r, ow = ow0 + cg;
+  if (oh < H) {
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+      const float bv = bias ? bias[co] : 0.f;
+      float* yp = y + (((size_t)b * COUT + co) * H + oh) * W + ow;
+      if (ow + 3 < W && (W & 3) == 0) {
+        *reinterpret_cast<f32x4*>(yp) = f32x4{acc[co][0] + bv, acc[co][1] + bv, acc[co][2] + bv, acc[co][3] + bv};
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          if (ow + p < W) yp[p] = acc[co][p] + bv;
+      }
+    }
+  }
+}
+
+template <int COUT>
+int launch_thin(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
+                hipStream_t st) {
+  const int tiles_w = cdiv(W, TW), tiles_h = cdiv(H, TH);
+  const long grid = (long)B * tiles_w * tiles_h;
+  if (grid <= 0 || grid > 0x7fffffffL) return VG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(convT_s1_thin_kernel<COUT>, dim3((unsigned)grid), dim3(NT), 0, st, x, w, bias, y, Cin, H, W,
+                     tiles_w, tiles_w * tiles_h);
+  VG_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+int vg_internal_convT_s1_thin(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H,
+                              int W, int Cout, hipStream_t st) {
+  switch (Cout) {
+    case 1: return launch_thin<1>(x, w, bias, y, B, Cin, H, W, st);
+    case 2: return launch_thin<2>(x, w, bias, y, B, Cin, H, W, st);
+    case 3: return launch_thin<3>(x, w, bias, y, B, Cin, H, W, st);
+    case 4: return launch_thin<4>(x, w, bias, y, B, Cin, H, W, st);
+    default: return VG_ERR_BAD_ARG;
+  }
+}

@@ -178,18 +178,28 @@ __global__ __launch_bounds__(WG_NT, 2) void conv5x5_wgrad_kernel(WArgs A) {
   }
 }
 
+// dw[i] = sum_k ws[k][i] in a fixed order.  A workgroup owns 64 consecutive elements; its 4
+// wavefronts each sum every 4th slab (coalesced 256-B rows), then combine through LDS in
+// wavefront order -- deterministic, and parallel over the slabs when there are many of them.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                            int n, int splits) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += ws[(size_t)k * n + i];
-  dw[i] = s;
+  if (i < n)
+    for (int k = wid; k < splits; k += 4) s += ws[(size_t)k * n + i];
+  red[wid][lane] = s;
+  __syncthreads();
+  if (wid == 0 && i < n) dw[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 struct Plan {
   int tw, tm, mtiles, ntiles, splits, tiles_w, tiles_hw, chunks, cps, OH, OW;
 };
+
+int g_wgrad_tm_override = -1;       // diagnostics only (vg_debug_set_conv_tile mode 2)
+int g_wgrad_blocks_target = -1;     // diagnostics only
 
 Plan make_plan(int B, int Cin, int H, int W, int Cout, int S) {
   Plan p;
@@ -197,13 +207,19 @@ Plan make_plan(int B, int Cin, int H, int W, int Cout, int S) {
   p.OW = (W - 1) / S + 1;
   p.tw = p.OW <= 8 ? 8 : (p.OW <= 16 ? 16 : (p.OW <= 32 ? 32 : 64));
   p.tm = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
+  if (p.tm == 128 && Cout <= 128 && Cin <= 32) p.tm = 64;   // few column tiles: more row tiles instead
+  if (g_wgrad_tm_override > 0 && g_wgrad_tm_override <= p.tm) p.tm = g_wgrad_tm_override;
   p.mtiles = cdiv(Cout, p.tm);
   p.ntiles = cdiv(Cin, CIT);
   const int th = KC / p.tw;
   p.tiles_w = cdiv(p.OW, p.tw);
   p.tiles_hw = p.tiles_w * cdiv(p.OH, th);
   p.chunks = B * p.tiles_hw;
-  int want = cdiv(1024, p.mtiles * p.ntiles);
+  // split-K so that every layer fills the chip (measured, scripts/tune_wgrad.py): ~2048
+  // workgroups for the wide layers, fewer slabs for the thin ones (their cost is the reduction)
+  const int tiles = p.mtiles * p.ntiles;
+  int target = g_wgrad_blocks_target > 0 ? g_wgrad_blocks_target : (tiles >= 32 ? 2048 : (tiles >= 4 ? 1024 : 512));
+  int want = cdiv(target, tiles);
   if (want > p.chunks) want = p.chunks;
   if (want < 1) want = 1;
   p.cps = cdiv(p.chunks, want);
@@ -238,6 +254,13 @@ int dispatch_tw(const WArgs& A, int tw, int tm, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int vg_debug_set_wgrad(int what, int value) {
+  if (what == 0) g_wgrad_tm_override = value;
+  else if (what == 1) g_wgrad_blocks_target = value;
+  else return VG_ERR_BAD_ARG;
+  return 0;
+}
+
 extern "C" size_t vg_conv5x5_wgrad_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride) {
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return 0;
   const Plan p = make_plan(B, Cin, H, W, Cout, stride);
@@ -260,7 +283,7 @@ extern "C" int vg_conv5x5_wgrad(const float* x, const float* gy, float* dw, int 
   int rc = (stride == 2) ? dispatch_tw<2>(A, p.tw, p.tm, st) : dispatch_tw<1>(A, p.tw, p.tm, st);
   if (rc) return rc;
   const int n = Cout * Cin * 25;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)workspace, dw, n,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, (const float*)workspace, dw, n,
                      p.splits);
   VG_CHECK_LAUNCH();
   return 0;

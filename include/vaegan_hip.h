@@ -39,6 +39,14 @@ extern "C" {
 
 int vg_version(void);
 
+/* Diagnostics / tuning only: force tile variant `variant` (>= 0; -1 restores the
+ * heuristic) for mode 0 (vg_conv5x5_fwd) or 1 (vg_convT5x5_fwd).  Process-global;
+ * never used by the product path. */
+int vg_debug_set_conv_tile(int mode, int variant);
+/* Diagnostics / tuning only: what=0 caps the wgrad cout tile (32/64/128, -1 = heuristic);
+ * what=1 sets the split-K workgroup target (default 1024). */
+int vg_debug_set_wgrad(int what, int value);
+
 /* ---- 5x5 convolutions, padding 2, stride 1 or 2 ----------------------------
  * y[B,Cout,OH,OW] = conv2d(x[B,Cin,H,W], w[Cout,Cin,5,5]) + bias;  OH=(H-1)/s+1.
  * nn.Conv2d forward: model.py:450,453,456 (encoder), :389,392,395,398 (discr.).

@@ -1,0 +1,27 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from disentangle_mlp_amd import ops, _lib
+lib = _lib.load()
+B = 128
+L = [("dis.c3", 32, 128, 64, 2), ("dis.c6", 128, 256, 32, 2), ("dis.c9", 256, 256, 16, 2), ("enc.f3", 64, 128, 32, 2),
+     ("enc.f6", 128, 256, 16, 2), ("dis.c0", 3, 32, 64, 1), ("enc.f0", 3, 64, 64, 2)]
+def timeit(fn, n=10):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+for name, cin, cout, h, s in L:
+    x = torch.randn(B, cin, h, h, device="cuda")
+    gy = torch.randn(B, cout, h // s, h // s, device="cuda")
+    gf = 2.0 * B * (h // s) ** 2 * cin * cout * 25 / 1e9
+    res = []
+    for tm in (128, 64):
+        for tgt in (512, 1024, 2048):
+            lib.vg_debug_set_wgrad(0, tm); lib.vg_debug_set_wgrad(1, tgt)
+            ms = timeit(lambda: ops.conv5x5_wgrad(x, gy, s))
+            res.append(f"tm{tm}/b{tgt}:{ms*1e3:5.0f}us {gf/ms:5.1f}TF")
+    print(f"{name:7s} {gf:5.1f}GF " + " ".join(res), flush=True)
