@@ -208,37 +208,61 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
   }
 }
 
-// BatchNorm1d: x [B][C]; one thread per channel, lanes sweep consecutive channels
-// (coalesced); the second pass over the B rows is served from L2.
+// BatchNorm1d: x [B][C].  A workgroup owns 32 consecutive channels (128-byte coalesced rows);
+// its 8 row-slices (threads 32*s .. 32*s+31) each sum every 8th batch row in fp64 and combine
+// through LDS in a fixed order; the normalise / gradient pass re-reads the rows from L2.
+constexpr int B1_CH = 32, B1_SL = 8;
+
 __global__ __launch_bounds__(NT) void bn1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float* __restrict__ y,
                                                       float* __restrict__ running_mean,
                                                       float* __restrict__ running_var, float* __restrict__ save_mean,
                                                       float* __restrict__ save_invstd, int B, int C, float eps,
                                                       float momentum, int act) {
-  const int c = blockIdx.x * NT + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double r1[B1_SL][B1_CH], r2[B1_SL][B1_CH];
+  __shared__ float s_sc[B1_CH], s_sh[B1_CH];
+  const int cl = threadIdx.x % B1_CH, sl = threadIdx.x / B1_CH;
+  const int c = blockIdx.x * B1_CH + cl;
+  const bool cok = c < C;
   double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < B; ++b) {
-    const float v = x[(size_t)b * C + c];
-    s1 += v;
-    s2 += (double)v * v;
+  if (cok)
+    for (int b = sl; b < B; b += B1_SL) {
+      const float v = x[(size_t)b * C + c];
+      s1 += v;
+      s2 += (double)v * v;
+    }
+  r1[sl][cl] = s1;
+  r2[sl][cl] = s2;
+  __syncthreads();
+  if (sl == 0 && cok) {
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < B1_SL; ++k) {
+      t1 += r1[k][cl];
+      t2 += r2[k][cl];
+    }
+    const double m = t1 / B;
+    double var = t2 / B - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mu = (float)m, is = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[c] = mu;
+    save_invstd[c] = is;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    if (running_var) {
+      const double unb = B > 1 ? var * B / (B - 1.0) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+    const float sc = gamma[c] * is;
+    s_sc[cl] = sc;
+    s_sh[cl] = beta[c] - mu * sc;
   }
-  const double m = s1 / B;
-  double var = s2 / B - m * m;
-  if (var < 0.0) var = 0.0;
-  const float mu = (float)m, is = (float)(1.0 / sqrt(var + (double)eps));
-  save_mean[c] = mu;
-  save_invstd[c] = is;
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
-  if (running_var) {
-    const double unb = B > 1 ? var * B / (B - 1.0) : var;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
-  }
-  const float sc = gamma[c] * is, sh = beta[c] - mu * sc;
-  for (int b = 0; b < B; ++b) {
-    const size_t o = (size_t)b * C + c;
-    y[o] = act_fwd(fmaf(x[o], sc, sh), act);
+  __syncthreads();
+  if (cok) {
+    const float sc = s_sc[cl], sh = s_sh[cl];
+    for (int b = sl; b < B; b += B1_SL) {
+      const size_t o = (size_t)b * C + c;
+      y[o] = act_fwd(fmaf(x[o], sc, sh), act);
+    }
   }
 }
 
@@ -249,26 +273,50 @@ __global__ __launch_bounds__(NT) void bn1d_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ invstd, float* __restrict__ gx,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int B,
                                                       int C, int act) {
-  const int c = blockIdx.x * NT + threadIdx.x;
-  if (c >= C) return;
-  const float mu = mean[c], is = invstd[c];
-  const float sc = gamma[c] * is, sh = beta[c] - mu * sc;
+  __shared__ double r1[B1_SL][B1_CH], r2[B1_SL][B1_CH];
+  __shared__ float s_c1[B1_CH], s_c2[B1_CH];
+  const int cl = threadIdx.x % B1_CH, sl = threadIdx.x / B1_CH;
+  const int c = blockIdx.x * B1_CH + cl;
+  const bool cok = c < C;
+  float mu = 0.f, is = 0.f, sc = 0.f, sh = 0.f;
   double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < B; ++b) {
-    const size_t o = (size_t)b * C + c;
-    const float xv = x[o];
-    const float g = act_grad(fmaf(xv, sc, sh), gy[o], act);
-    s1 += g;
-    s2 += (double)(g * ((xv - mu) * is));
+  if (cok) {
+    mu = mean[c];
+    is = invstd[c];
+    sc = gamma[c] * is;
+    sh = beta[c] - mu * sc;
+    for (int b = sl; b < B; b += B1_SL) {
+      const size_t o = (size_t)b * C + c;
+      const float xv = x[o];
+      const float g = act_grad(fmaf(xv, sc, sh), gy[o], act);
+      s1 += g;
+      s2 += (double)(g * ((xv - mu) * is));
+    }
   }
-  if (dbeta) dbeta[c] = (float)s1;
-  if (dgamma) dgamma[c] = (float)s2;
-  const float c1 = (float)(s1 / B), c2 = (float)(s2 / B);
-  for (int b = 0; b < B; ++b) {
-    const size_t o = (size_t)b * C + c;
-    const float xv = x[o];
-    const float g = act_grad(fmaf(xv, sc, sh), gy[o], act);
-    gx[o] = sc * (g - c1 - ((xv - mu) * is) * c2);
+  r1[sl][cl] = s1;
+  r2[sl][cl] = s2;
+  __syncthreads();
+  if (sl == 0 && cok) {
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < B1_SL; ++k) {
+      t1 += r1[k][cl];
+      t2 += r2[k][cl];
+    }
+    if (dbeta) dbeta[c] = (float)t1;
+    if (dgamma) dgamma[c] = (float)t2;
+    s_c1[cl] = (float)(t1 / B);
+    s_c2[cl] = (float)(t2 / B);
+  }
+  __syncthreads();
+  if (cok) {
+    const float c1 = s_c1[cl], c2 = s_c2[cl];
+    for (int b = sl; b < B; b += B1_SL) {
+      const size_t o = (size_t)b * C + c;
+      const float xv = x[o];
+      const float g = act_grad(fmaf(xv, sc, sh), gy[o], act);
+      gx[o] = sc * (g - c1 - ((xv - mu) * is) * c2);
+    }
   }
 }
 
@@ -292,7 +340,7 @@ extern "C" int vg_bn_act_fwd(const float* x, const float* gamma, const float* be
   if (act < VG_ACT_NONE || act > VG_ACT_LRELU) return VG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (HW == 1) {
-    hipLaunchKernelGGL(bn1d_fwd_kernel, dim3(cdiv(C, NT)), dim3(NT), 0, st, x, gamma, beta, y, running_mean,
+    hipLaunchKernelGGL(bn1d_fwd_kernel, dim3(cdiv(C, B1_CH)), dim3(NT), 0, st, x, gamma, beta, y, running_mean,
                        running_var, save_mean, save_invstd, B, C, eps, momentum, act);
     VG_CHECK_LAUNCH();
     return 0;
@@ -324,7 +372,7 @@ extern "C" int vg_bn_act_bwd(const float* gy, const float* x, const float* gamma
   if (act < VG_ACT_NONE || act > VG_ACT_LRELU) return VG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (HW == 1) {
-    hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(cdiv(C, NT)), dim3(NT), 0, st, gy, x, gamma, beta, save_mean,
+    hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(cdiv(C, B1_CH)), dim3(NT), 0, st, gy, x, gamma, beta, save_mean,
                        save_invstd, gx, dgamma, dbeta, B, C, act);
     VG_CHECK_LAUNCH();
     return 0;

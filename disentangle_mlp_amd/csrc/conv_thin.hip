@@ -36,13 +36,28 @@ __global__ __launch_bounds__(NT) void convT_s1_thin_kernel(const float* __restri
     for (int p = 0; p < 4; ++p) acc[co][p] = 0.f;
 
   for (int c0 = 0; c0 < Cin; c0 += CK) {
-    // stage patch rows oh0-2 .. oh0+TH+1, cols ow0-2 .. ow0+TW+1 of CK channels
-    for (int e = tid; e < CK * PH * PWS; e += NT) {
-      const int col = e % PWS, t = e / PWS, pr = t % PH, c = t / PH;
-      const int ih = oh0 - 2 + pr, iw = ow0 - 2 + col;
-      const bool ok = (c0 + c) < Cin && ih >= 0 && ih < H && iw >= 0 && iw < W;
-      const float v = xb[ok ? (size_t)(c0 + c) * HW + ih * W + iw : 0];
-      patch[e] = ok ? v : 0.f;
+    // stage patch rows oh0-2 .. oh0+TH+1, cols ow0-2 .. ow0+TW+1 of CK channels: a wavefront
+    // copies one 68-float row per step (64 lanes + a 4-lane tail), no index division
+    {
+      const int lane = tid & 63, wid = tid >> 6;
+      for (int rr = wid; rr < CK * PH; rr += NT / 64) {
+        const int c = rr / PH, pr = rr - c * PH;
+        const int ih = oh0 - 2 + pr;
+        const bool rok = (c0 + c) < Cin && ih >= 0 && ih < H;
+        const float* src = xb + (rok ? (size_t)(c0 + c) * HW + (size_t)ih * W : 0);
+        {
+          const int iw = ow0 - 2 + lane;
+          const bool ok = rok && iw >= 0 && iw < W;
+          const float v = src[ok ? iw : 0];
+          patch[rr * PWS + lane] = ok ? v : 0.f;
+        }
+        if (lane < PWS - 64) {
+          const int iw = ow0 - 2 + 64 + lane;
+          const bool ok = rok && iw >= 0 && iw < W;
+          const float v = src[ok ? iw : 0];
+          patch[rr * PWS + 64 + lane] = ok ? v : 0.f;
+        }
+      }
     }
     __syncthreads();
     const int cmax = min(CK, Cin - c0);
