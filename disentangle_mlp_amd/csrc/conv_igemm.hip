@@ -30,11 +30,12 @@ namespace {
 
 enum { MODE_FWD = 0, MODE_TR = 1 };
 
-template <int MODE_, int S_, int NB_, int TH_, int TW_, int TN_, int WC_, int WP_, int CK_, int MINW_ = 2, int PIPE_ = 0>
+template <int MODE_, int S_, int NB_, int TH_, int TW_, int TN_, int WC_, int WP_, int CK_, int MINW_ = 2, int PIPE_ = 0,
+          int KS_ = 1>
 struct Cfg {
   static constexpr int MODE = MODE_, S = S_, NB = NB_, TH = TH_, TW = TW_, TN = TN_, WC = WC_, WP = WP_,
-                       CK = CK_, MINW = MINW_, PIPE = PIPE_;
-  static constexpr int NT = 64 * WC * WP;
+                       CK = CK_, MINW = MINW_, PIPE = PIPE_, KS = KS_;  // KS: in-workgroup split of the K chunk
+  static constexpr int NT = 64 * WC * WP * KS;
   static constexpr int TM = NB * TH * TW;
   static constexpr int FC = TN / 32 / WC;  // 32-row cout fragments per wave
   static constexpr int FP = TM / 32 / WP;  // 32-col pixel fragments per wave
@@ -50,6 +51,8 @@ struct Cfg {
   static constexpr int NCLS = (MODE == MODE_FWD) ? 1 : S * S;
   static_assert(TN % (32 * WC) == 0 && TM % (32 * WP) == 0 && CK % 2 == 0, "tile shape");
   static_assert(RLMAX <= NT, "one filter row per pass at least");
+  static_assert(KS == 1 || (CK / 2) % KS == 0, "split-K groups own whole channel pairs");
+  static_assert(KS == 1 || 2 * STAGE >= (KS - 1) * TM * TN, "LDS must hold the partial tiles of the K groups");
 };
 
 struct Args {
@@ -78,7 +81,8 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int h = lane >> 5, l32 = lane & 31;
-  const int wc = wid % C::WC, wp = wid / C::WC;
+  const int kg = wid / (C::WC * C::WP), w2 = wid % (C::WC * C::WP);   // K group, wave within the tile
+  const int wc = w2 % C::WC, wp = w2 / C::WC;
   const int nt = bid % A.ntiles_n;  // blocks sharing an XCD (bid % 8) share a filter slab when ntiles_n | 8
   bid /= A.ntiles_n;
   const int sp = bid % A.tiles_hw, bg = bid / A.tiles_hw;
@@ -158,13 +162,14 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
 
   // ---- per-lane operand bases
   int base_w[FC], base_p[FP];
+  constexpr int CPG = CK / 2 / C::KS;   // channel pairs per K group
 #pragma unroll
-  for (int g = 0; g < FC; ++g) base_w[g] = NP + ((wc * FC + g) * 32 + l32) * WS + h * NTAP;
+  for (int g = 0; g < FC; ++g) base_w[g] = NP + ((wc * FC + g) * 32 + l32) * WS + h * NTAP + kg * CPG * 2 * NTAP;
 #pragma unroll
   for (int f = 0; f < FP; ++f) {
     const int m = (wp * FP + f) * 32 + l32;
     const int nb = m / (TH * TW), r = m % (TH * TW);
-    base_p[f] = ((nb * CK + h) * PH + PSTEP * (r / TW)) * PWP + PSTEP * (r % TW);
+    base_p[f] = ((nb * CK + h + kg * CPG * 2) * PH + PSTEP * (r / TW)) * PWP + PSTEP * (r % TW);
   }
 
   f32x16 acc[FC][FP];
@@ -185,7 +190,7 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
     const bool more = (ch + 1) < nchunks;
     if (more) load_chunk((ch + 1) * CK);
     // (cp, tap) steps, operands of step t+1 read from LDS before the MFMAs of step t issue
-    constexpr int NSTEP = (CK / 2) * NTAP;
+    constexpr int NSTEP = CPG * NTAP;
     float a_cur[FC], b_cur[FP], a_nxt[FC], b_nxt[FP];
     auto read_step = [&](int stp, float* a, float* b) {
       const int cp = stp / NTAP, t = stp % NTAP;
@@ -226,6 +231,31 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
     __syncthreads();
   }
 
+  // ---- in-workgroup split-K: groups 1..KS-1 park their partial tiles in LDS, group 0 adds them
+  if constexpr (C::KS > 1) {
+    constexpr int PER_WAVE = FC * FP * 16 * 64;
+    if (kg > 0) {
+      float* dst = smem + ((kg - 1) * C::WC * C::WP + w2) * PER_WAVE + lane;
+#pragma unroll
+      for (int g = 0; g < FC; ++g)
+#pragma unroll
+        for (int f = 0; f < FP; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[((g * FP + f) * 16 + r) * 64] = acc[g][f][r];
+    }
+    __syncthreads();
+    if (kg > 0) return;
+#pragma unroll
+    for (int k = 1; k < C::KS; ++k) {
+      const float* src = smem + ((k - 1) * C::WC * C::WP + w2) * PER_WAVE + lane;
+#pragma unroll
+      for (int g = 0; g < FC; ++g)
+#pragma unroll
+        for (int f = 0; f < FP; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[g][f][r] += src[((g * FP + f) * 16 + r) * 64];
+    }
+  }
   // ---- epilogue: + bias, NCHW store
   const int YH = A.YH, YW = A.YW;
 #pragma unroll
@@ -299,38 +329,38 @@ int launch(const float* x, const float* w, const float* bias, float* y, int B, i
 // ---- tile variants ------------------------------------------------------------------
 // Geometry by tile-space width: W32 -> rows of 32 pixels, W16 -> 16, W8 -> 8x8 images.
 //   variant 0: 128 px x 128 cout, CK 2 (fwd) / 4 (tr)     variant 3: 128 px x 64 cout, CK 2 / 4
-//   variant 1: 128 px x 64 cout, pinned LDS prefetch      variant 4: 128 px x 64 cout, CK 4 / 8
-//   variant 2: 64 px x 64 cout                            variant 5: 128 px x 128 cout, pinned prefetch
+//   variant 1: 128 px x 64 cout, pinned LDS prefetch      variant 4: 64 px x 64 cout, 8 waves (K split 2)
+//   variant 2: 64 px x 64 cout                            variant 5: 128 px x 64 cout, 8 waves (K split 2)
 //   variant 6: 128 px x 32 cout (thin outputs), 4 waves along the pixels
 template <int MODE, int S, int WIDTH, int VAR>
 struct Pick;
-#define VG_PICK(WIDTH, VAR, NB, TH, TW, TN, WC, WP, CKF, CKT, PIPE)                                         \
+#define VG_PICK(WIDTH, VAR, NB, TH, TW, TN, WC, WP, CKF, CKT, PIPE, KS)                                         \
   template <int MODE, int S>                                                                              \
   struct Pick<MODE, S, WIDTH, VAR> {                                                                      \
-    using type = Cfg<MODE, S, NB, TH, TW, TN, WC, WP, ((MODE == MODE_FWD || S == 1) ? CKF : CKT), 2, PIPE>; \
+    using type = Cfg<MODE, S, NB, TH, TW, TN, WC, WP, ((MODE == MODE_FWD || S == 1) ? CKF : CKT), 2, PIPE, KS>; \
   };
-//       W  V NB TH TW   TN WC WP CKF CKT PIPE
-VG_PICK(32, 0, 1, 4, 32, 128, 2, 2, 2, 4, 0)
-VG_PICK(16, 0, 1, 8, 16, 128, 2, 2, 2, 4, 0)
-VG_PICK(8, 0, 2, 8, 8, 128, 2, 2, 2, 4, 0)
-VG_PICK(32, 1, 1, 4, 32, 64, 2, 2, 2, 4, 1)
-VG_PICK(16, 1, 1, 8, 16, 64, 2, 2, 2, 4, 1)
-VG_PICK(8, 1, 2, 8, 8, 64, 2, 2, 2, 4, 1)
-VG_PICK(32, 2, 1, 2, 32, 64, 2, 2, 2, 4, 0)
-VG_PICK(16, 2, 1, 4, 16, 64, 2, 2, 2, 4, 0)
-VG_PICK(8, 2, 1, 8, 8, 64, 2, 2, 2, 4, 0)
-VG_PICK(32, 3, 1, 4, 32, 64, 2, 2, 2, 4, 0)
-VG_PICK(16, 3, 1, 8, 16, 64, 2, 2, 2, 4, 0)
-VG_PICK(8, 3, 2, 8, 8, 64, 2, 2, 2, 4, 0)
-VG_PICK(32, 4, 1, 4, 32, 64, 2, 2, 4, 8, 0)
-VG_PICK(16, 4, 1, 8, 16, 64, 2, 2, 4, 8, 0)
-VG_PICK(8, 4, 2, 8, 8, 64, 2, 2, 4, 8, 0)
-VG_PICK(32, 5, 1, 4, 32, 128, 2, 2, 2, 4, 1)
-VG_PICK(16, 5, 1, 8, 16, 128, 2, 2, 2, 4, 1)
-VG_PICK(8, 5, 2, 8, 8, 128, 2, 2, 2, 4, 1)
-VG_PICK(32, 6, 1, 4, 32, 32, 1, 4, 2, 4, 0)
-VG_PICK(16, 6, 1, 8, 16, 32, 1, 4, 2, 4, 0)
-VG_PICK(8, 6, 2, 8, 8, 32, 1, 4, 2, 4, 0)
+//       W  V NB TH TW   TN WC WP CKF CKT PIPE KS
+VG_PICK(32, 0, 1, 4, 32, 128, 2, 2, 2, 4, 0, 1)
+VG_PICK(16, 0, 1, 8, 16, 128, 2, 2, 2, 4, 0, 1)
+VG_PICK(8, 0, 2, 8, 8, 128, 2, 2, 2, 4, 0, 1)
+VG_PICK(32, 1, 1, 4, 32, 64, 2, 2, 2, 4, 1, 1)
+VG_PICK(16, 1, 1, 8, 16, 64, 2, 2, 2, 4, 1, 1)
+VG_PICK(8, 1, 2, 8, 8, 64, 2, 2, 2, 4, 1, 1)
+VG_PICK(32, 2, 1, 2, 32, 64, 2, 2, 2, 4, 0, 1)
+VG_PICK(16, 2, 1, 4, 16, 64, 2, 2, 2, 4, 0, 1)
+VG_PICK(8, 2, 1, 8, 8, 64, 2, 2, 2, 4, 0, 1)
+VG_PICK(32, 3, 1, 4, 32, 64, 2, 2, 2, 4, 0, 1)
+VG_PICK(16, 3, 1, 8, 16, 64, 2, 2, 2, 4, 0, 1)
+VG_PICK(8, 3, 2, 8, 8, 64, 2, 2, 2, 4, 0, 1)
+VG_PICK(32, 4, 1, 2, 32, 64, 2, 2, 4, 8, 0, 2)
+VG_PICK(16, 4, 1, 4, 16, 64, 2, 2, 4, 8, 0, 2)
+VG_PICK(8, 4, 1, 8, 8, 64, 2, 2, 4, 8, 0, 2)
+VG_PICK(32, 5, 1, 4, 32, 64, 2, 2, 4, 8, 0, 2)
+VG_PICK(16, 5, 1, 8, 16, 64, 2, 2, 4, 8, 0, 2)
+VG_PICK(8, 5, 2, 8, 8, 64, 2, 2, 4, 8, 0, 2)
+VG_PICK(32, 6, 1, 4, 32, 32, 1, 4, 2, 4, 0, 1)
+VG_PICK(16, 6, 1, 8, 16, 32, 1, 4, 2, 4, 0, 1)
+VG_PICK(8, 6, 2, 8, 8, 32, 1, 4, 2, 4, 0, 1)
 #undef VG_PICK
 constexpr int NVAR = 7;
 
@@ -358,10 +388,19 @@ int dispatch(const float* x, const float* w, const float* bias, float* y, int B,
   const int tsw = (MODE == MODE_FWD) ? (XW - 1) / S + 1 : XW;
   const int tsh = (MODE == MODE_FWD) ? (XH - 1) / S + 1 : XH;
   const int width = tsw >= 32 ? 32 : (tsw >= 16 ? 16 : 8);
-  // Measured on MI355X at B=128 (scripts/tune_conv.py): 128 px x 64 cout with the shallow K chunk
-  // wins or ties on every heavy layer (4 resident workgroups per CU hide the staging).
-  const int var = (Cout <= 32) ? 6 : 3;
-  (void)tsh;
+  // Measured on MI355X at B=128 (scripts/tune_conv.py): the 128 px x 64 cout tile wins or ties on
+  // every heavy layer.  The 8-wave form (in-workgroup split of the K chunk) doubles the resident
+  // waves per tile: it wins for the forward kernel everywhere and for the transposed kernel when
+  // the 4-wave grid would leave SIMDs with a single wave (< 768 workgroups).
+  int var;
+  if (Cout <= 32) {
+    var = 6;
+  } else if (MODE == MODE_FWD) {
+    var = 5;
+  } else {
+    const long blocks = (long)cdiv(B * cdiv(tsh, 8) * cdiv(tsw, 8) * 64, 128) * cdiv(Cout, 64) * S * S;
+    var = blocks < 768 ? 5 : 3;
+  }
   const int ov = g_tile_override[MODE];
   const int use = (ov >= 0 && ov < NVAR) ? ov : var;
   if (width == 32) return launch_var<MODE, S, 32>(use, x, w, bias, y, B, Cin, XH, XW, Cout, st);
