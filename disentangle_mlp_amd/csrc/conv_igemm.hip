@@ -83,9 +83,26 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
   const int h = lane >> 5, l32 = lane & 31;
   const int kg = wid / (C::WC * C::WP), w2 = wid % (C::WC * C::WP);   // K group, wave within the tile
   const int wc = w2 % C::WC, wp = w2 / C::WC;
-  const int nt = bid % A.ntiles_n;  // blocks sharing an XCD (bid % 8) share a filter slab when ntiles_n | 8
-  bid /= A.ntiles_n;
-  const int sp = bid % A.tiles_hw, bg = bid / A.tiles_hw;
+  // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (bid % 8 labels the
+  // XCD, each with its own L2).  The ntiles_n cout tiles that read the SAME input patch are
+  // given to ONE XCD, back to back, so the patch is fetched from HBM once and re-read from that
+  // L2; every XCD streams the whole (L2-sized) filter.  Placement affects speed only.
+  int nt, pt;
+  {
+    const int ntn = A.ntiles_n;
+    const int npatch = A.blocks_per_cls / ntn;
+    const int full = (npatch / 8) * 8 * ntn;
+    if (bid < full) {
+      const int xcd = bid & 7, j = bid >> 3;
+      pt = (j / ntn) * 8 + xcd;
+      nt = j % ntn;
+    } else {
+      const int t = bid - full;
+      pt = (npatch / 8) * 8 + t / ntn;
+      nt = t % ntn;
+    }
+  }
+  const int sp = pt % A.tiles_hw, bg = pt / A.tiles_hw;
   const int th0 = (sp / A.tiles_w) * TH, tw0 = (sp % A.tiles_w) * TW;  // tile origin (tile space)
   const int b0 = bg * NB, n0 = nt * TN;
   const int Cin = A.Cin, Cout = A.Cout, XH = A.XH, XW = A.XW;

@@ -42,26 +42,88 @@ class ModelOpt:
 
 
 class FlatGrads:
-    """All gradients of a network as views into one contiguous fp32 buffer, so a phase's
-    gradient exchange is a single large all-reduce over xGMI."""
+    """All gradients of a network as views into one contiguous fp32 buffer, exchanged with
+    bucketed RCCL all-reduces (SUM) that overlap the rest of the backward pass.
 
-    def __init__(self, params):
+    The buffer follows parameter order; buckets are contiguous slices of ~`bucket_bytes`, cut
+    from the END of the parameter list (the layers whose gradients autograd finishes first).
+    A post-accumulate-grad hook counts a bucket's parameters down; when the last one is ready the
+    bucket's all-reduce is enqueued asynchronously (it runs on RCCL's stream, ordered after the
+    kernels that produced those gradients).  `finish()` reduces whatever did not fire and waits.
+    xGMI is point-to-point (7 links x ~153 GB/s per GPU): a few large buckets keep every ring /
+    tree RCCL builds busy, and the 134 MB Linear-weight buckets -- ready first in backward -- hide
+    behind the convolution backward."""
+
+    def __init__(self, params, bucket_bytes=96 << 20, overlap=True):
         self.params = [p for p in params]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.views, self.offsets = [], []
         off = 0
-        self.views = []
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            self.offsets.append(off)
             off += p.numel()
+        # buckets from the last parameter backwards
+        self.buckets = []          # dicts: start, end (element offsets), members (param indices)
+        cap = max(1, bucket_bytes // 4)
+        cur = None
+        for i in reversed(range(len(self.params))):
+            if cur is None or (cur["end"] - self.offsets[i]) > cap and cur["members"]:
+                cur = dict(start=self.offsets[i], end=self.offsets[i] + self.params[i].numel(), members=[])
+                self.buckets.append(cur)
+            cur["start"] = self.offsets[i]
+            cur["members"].append(i)
+        self.bucket_of = {}
+        for b_i, b in enumerate(self.buckets):
+            for i in b["members"]:
+                self.bucket_of[i] = b_i
+        self.overlap = overlap
+        self._pending, self._launched, self._handles = [], [], []
+        self._armed = False
+        self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
+
+    def _make_hook(self, i):
+        def hook(_p):
+            if not self._armed:
+                return
+            b = self.bucket_of[i]
+            self._pending[b] -= 1
+            if self._pending[b] == 0 and self.overlap:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        bk = self.buckets[b]
+        self._launched[b] = True
+        self._handles.append(dist.all_reduce(self.flat[bk["start"]:bk["end"]], op=dist.ReduceOp.SUM,
+                                             async_op=True))
 
     def zero_and_attach(self):
         self.flat.zero_()
         for p, v in zip(self.params, self.views):
             p.grad = v
+        self._pending = [len(b["members"]) for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
+        self._armed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def finish(self):
+        """Reduce the buckets whose hooks did not all fire (or all of them without overlap), then
+        make the current stream wait for every exchange."""
+        if not self._armed:
+            return
+        for b in range(len(self.buckets)):
+            if not self._launched[b]:
+                self._launch(b)
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        self._armed = False
 
     def all_reduce(self, group=None):
+        """Single synchronous all-reduce of the whole buffer (no bucketing)."""
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
 
 
@@ -108,7 +170,7 @@ class BetaVAEGANTrainer:
 
     def _exchange(self, flat):
         if flat is not None and self.world > 1:
-            flat.all_reduce()
+            flat.finish()
 
     def _set_d_frozen(self, frozen):
         for p in self.netD.parameters():
@@ -235,7 +297,7 @@ class VAETrainer:
         mse = F.reconstruction_loss(recon, data)
         torch.autograd.backward([mse, kld])
         if self.flat is not None:
-            self.flat.all_reduce()
+            self.flat.finish()
         self.optimizer.step()
         return dict(mse=mse.detach(), kld=kld.detach())
 

@@ -88,7 +88,7 @@ def _dp_worker(rank, world, port, batch, q):
     flat.zero_and_attach()
     for p, gi in zip(d.parameters(), g):
         p.grad.add_(gi)                      # what autograd's accumulation does in the trainer
-    flat.all_reduce()
+    flat.finish()                            # no hook fired (no backward here): every bucket reduced now
     if rank == 0:
         q.put(flat.flat.clone())
     dist.barrier()
@@ -116,3 +116,57 @@ def test_two_rank_gradient_allreduce_equals_two_replica_emulation():
     assert got.shape == want.shape == (36122945,)
     err = float((got - want).norm() / want.norm())
     assert err <= 1e-6, err
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from disentangle_mlp_amd.trainer import FlatGrads
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(40, 64), torch.nn.ReLU(), torch.nn.Linear(64, 64), torch.nn.ReLU(),
+                              torch.nn.Linear(64, 8))
+    unused = torch.nn.Parameter(torch.zeros(5))            # never receives a gradient: finish() must cover it
+    params = list(net.parameters()) + [unused]
+    flat = FlatGrads(params, bucket_bytes=4096 * 4, overlap=True)
+    assert len(flat.buckets) >= 3
+    res = []
+    for it in range(2):                                    # two phases reuse the same buffers
+        flat.zero_and_attach()
+        g = torch.Generator().manual_seed(100 * it + rank)
+        x = torch.randn(16, 40, generator=g)
+        net(x).pow(2).sum().backward()
+        fired_early = sum(flat._launched)
+        flat.finish()
+        res.append((flat.flat.clone(), fired_early))
+    if rank == 0:
+        q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_overlapped_allreduce_two_ranks():
+    """The bucketed, hook-driven gradient exchange (what runs over RCCL on the GPUs) with 2 gloo
+    ranks equals the sum of the two ranks' gradients; buckets fire during backward."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for it, (got, fired_early) in enumerate(res):
+        assert fired_early >= 2                            # overlap: launched from the hooks
+        want = None
+        for r in range(world):
+            torch.manual_seed(0)
+            net = torch.nn.Sequential(torch.nn.Linear(40, 64), torch.nn.ReLU(), torch.nn.Linear(64, 64),
+                                      torch.nn.ReLU(), torch.nn.Linear(64, 8))
+            g = torch.Generator().manual_seed(100 * it + r)
+            net(torch.randn(16, 40, generator=g)).pow(2).sum().backward()
+            flat = torch.cat([p.grad.flatten() for p in net.parameters()] + [torch.zeros(5)])
+            want = flat if want is None else want + flat
+        assert torch.allclose(got, want, rtol=1e-6, atol=1e-6)
