@@ -39,6 +39,24 @@ def conv_flops(key):
     return 2.0 * B * oh * ow * Cin * Cout * 25   # conv_fwd and conv_wgrad
 
 
+def pmc_traffic(dominant):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass
+    (profiles/r01_pmc_dominant_conv_fwd.json: FETCH_SIZE x2 (gfx950 correction, calibrated) +
+    WRITE_SIZE).  Counters cannot be collected from inside this process, so the figure is the
+    profile's; it is reported only when it is for exactly this launch shape."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_dominant_conv_fwd.json")
+    try:
+        with open(path) as f:
+            pmc = json.load(f)
+    except OSError:
+        return None, None
+    L = pmc["launch"]
+    key = (L["op"], L["B"], L["Cin"], L["H"], L["W"], L["Cout"], L["stride"])
+    if tuple(dominant) != key:
+        return None, None
+    return pmc["hbm_bytes_per_launch"], "profiles/r01_pmc_dominant_conv_fwd.json"
+
+
 def cpu_baseline(batch, beta):
     """The oracle (CPU restatement of the reference's path) timed on this host's cores on a
     bounded sample: one iteration at the benchmark's per-GPU batch after a small warm-up."""
@@ -134,8 +152,10 @@ def main():
         if dominant and dom_ms:
             avg_ms = sum(dom_ms) / len(dom_ms)
             ach = conv_flops(dominant) / (avg_ms * 1e-3) / 1e12
+            traffic, tsrc = pmc_traffic(dominant)
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+                    "traffic_source": tsrc,
                     "kernel": "conv5x5_igemm_kernel" if dominant[0] != "conv_wgrad" else "conv5x5_wgrad_kernel",
                     "launch": {"op": dominant[0], "B": dominant[1], "Cin": dominant[2], "H": dominant[3],
                                "W": dominant[4], "Cout": dominant[5], "stride": dominant[6]},
