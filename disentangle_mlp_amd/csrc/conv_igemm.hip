@@ -218,7 +218,8 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
 #pragma unroll
       for (int f = 0; f < FP; ++f) b[f] = st[base_p[f] + (2 * cp * PH + ro) * PWP + cof];
     };
-    if constexpr (C::PIPE) {
+    if constexpr (C::PIPE == 2) __builtin_amdgcn_s_setprio(2);
+    if constexpr (C::PIPE == 1) {
       read_step(0, a_cur, b_cur);
 #pragma unroll
       for (int stp = 0; stp < NSTEP; ++stp) {
@@ -244,6 +245,7 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
           for (int f = 0; f < FP; ++f) acc[g][f] = mfma32(a_cur[g], b_cur[f], acc[g][f]);
       }
     }
+    if constexpr (C::PIPE == 2) __builtin_amdgcn_s_setprio(0);
     if (more) store_chunk(smem + ((ch + 1) & 1) * C::STAGE, (ch + 1) * CK);
     __syncthreads();
   }
@@ -346,7 +348,7 @@ int launch(const float* x, const float* w, const float* bias, float* y, int B, i
 // ---- tile variants ------------------------------------------------------------------
 // Geometry by tile-space width: W32 -> rows of 32 pixels, W16 -> 16, W8 -> 8x8 images.
 //   variant 0: 128 px x 128 cout, CK 2 (fwd) / 4 (tr)     variant 3: 128 px x 64 cout, CK 2 / 4
-//   variant 1: 128 px x 64 cout, pinned LDS prefetch      variant 4: 64 px x 64 cout, 8 waves (K split 2)
+//   variant 1: variant 5 + raised MFMA-phase priority     variant 4: 64 px x 64 cout, 8 waves (K split 2)
 //   variant 2: 64 px x 64 cout                            variant 5: 128 px x 64 cout, 8 waves (K split 2)
 //   variant 6: 128 px x 32 cout (thin outputs), 4 waves along the pixels
 template <int MODE, int S, int WIDTH, int VAR>
@@ -360,9 +362,9 @@ struct Pick;
 VG_PICK(32, 0, 1, 4, 32, 128, 2, 2, 2, 4, 0, 1)
 VG_PICK(16, 0, 1, 8, 16, 128, 2, 2, 2, 4, 0, 1)
 VG_PICK(8, 0, 2, 8, 8, 128, 2, 2, 2, 4, 0, 1)
-VG_PICK(32, 1, 1, 4, 32, 64, 2, 2, 2, 4, 1, 1)
-VG_PICK(16, 1, 1, 8, 16, 64, 2, 2, 2, 4, 1, 1)
-VG_PICK(8, 1, 2, 8, 8, 64, 2, 2, 2, 4, 1, 1)
+VG_PICK(32, 1, 1, 4, 32, 64, 2, 2, 4, 8, 2, 2)
+VG_PICK(16, 1, 1, 8, 16, 64, 2, 2, 4, 8, 2, 2)
+VG_PICK(8, 1, 2, 8, 8, 64, 2, 2, 4, 8, 2, 2)
 VG_PICK(32, 2, 1, 2, 32, 64, 2, 2, 2, 4, 0, 1)
 VG_PICK(16, 2, 1, 4, 16, 64, 2, 2, 2, 4, 0, 1)
 VG_PICK(8, 2, 1, 8, 8, 64, 2, 2, 2, 4, 0, 1)

@@ -24,16 +24,18 @@ constexpr int WG_NT = 256;
 constexpr int CIT = 5;    // input channels per column tile (125 of 128 columns used)
 constexpr int KC = 64;    // output pixels per K chunk
 
-template <int S_, int TW_, int TM_>
+template <int S_, int TW_, int TM_, int KS_ = 1>
 struct WCfg {
-  static constexpr int S = S_, TW = TW_, TH = KC / TW_, TM = TM_;
+  static constexpr int S = S_, TW = TW_, TH = KC / TW_, TM = TM_, KS = KS_;
+  static constexpr int NT = WG_NT * KS;   // KS wave groups split the 64-pixel K chunk
   static constexpr int WM = (TM >= 64) ? 2 : 1, WN = 4 / WM;
   static constexpr int FC = TM / 32 / WM, FN = 128 / 32 / WN;
   static constexpr int PH = S * (TH - 1) + 5, PW = S * (TW - 1) + 5, PWP = PW | 1;
   static constexpr int NPATCH = CIT * PH * PWP;
   static constexpr int AS = KC + 1;
   static constexpr int STAGE = TM * AS + NPATCH;
-  static constexpr int NQP = cdiv(NPATCH, WG_NT), NQA = TM / 4;
+  static constexpr int NQP = cdiv(NPATCH, NT), NQA = TM / (NT / 64);
+  static_assert(KS == 1 || STAGE >= 4 * (128 / 32 / (4 / WM)) * 16 * 64, "LDS holds one fragment row of partials per wave");
 };
 
 struct WArgs {
@@ -45,7 +47,7 @@ struct WArgs {
 };
 
 template <class C>
-__global__ __launch_bounds__(WG_NT, 2) void conv5x5_wgrad_kernel(WArgs A) {
+__global__ __launch_bounds__(C::NT, 2) void conv5x5_wgrad_kernel(WArgs A) {
   constexpr int S = C::S, TW = C::TW, TH = C::TH, TM = C::TM, FC = C::FC, FN = C::FN;
   constexpr int PH = C::PH, PW = C::PW, PWP = C::PWP, NPATCH = C::NPATCH, AS = C::AS;
   constexpr int NQP = C::NQP, NQA = C::NQA;
@@ -55,7 +57,9 @@ __global__ __launch_bounds__(WG_NT, 2) void conv5x5_wgrad_kernel(WArgs A) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int h = lane >> 5, l32 = lane & 31;
-  const int wm = wid % C::WM, wn = wid / C::WM;
+  const int kg = wid / 4, w4 = wid % 4;   // K group, wave within the output tile
+  const int wm = w4 % C::WM, wn = w4 / C::WM;
+  constexpr int NT = C::NT, NWV = C::NT / 64;
   int bid = blockIdx.x;
   const int mt = bid % A.mtiles;
   bid /= A.mtiles;
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(WG_NT, 2) void conv5x5_wgrad_kernel(WArgs A) {
   int pk[NQP], prc[NQP];
 #pragma unroll
   for (int q = 0; q < NQP; ++q) {
-    const int e = tid + q * WG_NT;
+    const int e = tid + q * NT;
     const int col = e % PWP;
     int t = e / PWP;
     const int r = t % PH, ci_l = t / PH;
@@ -97,29 +101,32 @@ __global__ __launch_bounds__(WG_NT, 2) void conv5x5_wgrad_kernel(WArgs A) {
     const float* gb = A.gy + ((size_t)b * Cout + m0 + wid) * OHW + oh * OW + ow;
 #pragma unroll
     for (int q = 0; q < NQA; ++q) {
-      const bool ok = pok && (m0 + wid + 4 * q) < Cout;
-      areg[q] = ok ? gb[(size_t)q * 4 * OHW] : 0.f;
+      const bool ok = pok && (m0 + wid + NWV * q) < Cout;
+      areg[q] = ok ? gb[(size_t)q * NWV * OHW] : 0.f;
     }
   };
   auto store_chunk = [&]() {
 #pragma unroll
     for (int q = 0; q < NQP; ++q) {
-      const int e = tid + q * WG_NT;
+      const int e = tid + q * NT;
       if (e < NPATCH) pl[e] = preg[q];
     }
 #pragma unroll
-    for (int q = 0; q < NQA; ++q) gyl[(wid + 4 * q) * AS + a_pix] = areg[q];
+    for (int q = 0; q < NQA; ++q) gyl[(wid + NWV * q) * AS + a_pix] = areg[q];
   };
 
   // ---- per-lane operand bases
   int base_a[FC], base_b[FN];
+  constexpr int KPG = KC / 2 / C::KS;            // pixel pairs per K group
+  constexpr int K0 = 2 * KPG;                    // first pixel of group 1
+  constexpr int IMM0 = (S * (K0 / TW)) * PWP + S * (K0 % TW);
 #pragma unroll
-  for (int g = 0; g < FC; ++g) base_a[g] = ((wm * FC + g) * 32 + l32) * AS + h;
+  for (int g = 0; g < FC; ++g) base_a[g] = ((wm * FC + g) * 32 + l32) * AS + h + kg * K0;
 #pragma unroll
   for (int f = 0; f < FN; ++f) {
     const int n = (wn * FN + f) * 32 + l32;
     const int ci_l = n / 25, tap = n % 25;
-    base_b[f] = (n < CIT * 25) ? TM * AS + (ci_l * PH + tap / 5) * PWP + tap % 5 + h * S : TM * AS;
+    base_b[f] = (n < CIT * 25) ? TM * AS + (ci_l * PH + tap / 5) * PWP + tap % 5 + h * S + kg * IMM0 : TM * AS;
   }
 
   f32x16 acc[FC][FN];
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(WG_NT, 2) void conv5x5_wgrad_kernel(WArgs A) {
       const bool more = (ch + 1) < c_end;
       if (more) load_chunk(ch + 1);
 #pragma unroll
-      for (int kp = 0; kp < KC / 2; ++kp) {
+      for (int kp = 0; kp < KPG; ++kp) {
         const int k = 2 * kp;
         const int imm_b = (S * (k / TW)) * PWP + S * (k % TW);
         float a[FC], b[FN];
@@ -161,6 +168,31 @@ __global__ __launch_bounds__(WG_NT, 2) void conv5x5_wgrad_kernel(WArgs A) {
     }
   }
 
+  // ---- in-workgroup K split: group 1 parks its partial tile in LDS (one 32-row fragment row at
+  // a time: FN*16*64 floats per wave), group 0 adds it
+  if constexpr (C::KS > 1) {
+    static_assert(C::KS == 2, "two K groups");
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < FC; ++g) {
+      float* slot = smem + (w4 * FN * 16) * 64 + lane;
+      if (kg == 1) {
+#pragma unroll
+        for (int f = 0; f < FN; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) slot[(f * 16 + r) * 64] = acc[g][f][r];
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int f = 0; f < FN; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[g][f][r] += slot[(f * 16 + r) * 64];
+      }
+      __syncthreads();
+    }
+    if (kg == 1) return;
+  }
   // ---- partial slab store: ws[split][co][ci*25+tap] (lanes = consecutive n: coalesced)
   float* wsb = A.ws + (size_t)split * Cout * Cin * 25;
 #pragma unroll
@@ -198,6 +230,7 @@ struct Plan {
   int tw, tm, mtiles, ntiles, splits, tiles_w, tiles_hw, chunks, cps, OH, OW;
 };
 
+int g_wgrad_ks = 2;                 // 8-wave K-split kernel for the 128-row tile (1 = 4-wave form, diagnostics)
 int g_wgrad_tm_override = -1;       // diagnostics only (vg_debug_set_conv_tile mode 2)
 int g_wgrad_blocks_target = -1;     // diagnostics only
 
@@ -230,14 +263,14 @@ Plan make_plan(int B, int Cin, int H, int W, int Cout, int S) {
 template <class C>
 int launch_w(const WArgs& A, hipStream_t st) {
   const long grid = (long)A.mtiles * A.ntiles * A.splits;
-  hipLaunchKernelGGL(conv5x5_wgrad_kernel<C>, dim3((unsigned)grid), dim3(WG_NT), 0, st, A);
+  hipLaunchKernelGGL(conv5x5_wgrad_kernel<C>, dim3((unsigned)grid), dim3(C::NT), 0, st, A);
   VG_CHECK_LAUNCH();
   return 0;
 }
 
 template <int S, int TW>
 int dispatch_tm(const WArgs& A, int tm, hipStream_t st) {
-  if (tm == 128) return launch_w<WCfg<S, TW, 128>>(A, st);
+  if (tm == 128) return g_wgrad_ks == 2 ? launch_w<WCfg<S, TW, 128, 2>>(A, st) : launch_w<WCfg<S, TW, 128>>(A, st);
   if (tm == 64) return launch_w<WCfg<S, TW, 64>>(A, st);
   return launch_w<WCfg<S, TW, 32>>(A, st);
 }
@@ -257,6 +290,7 @@ int dispatch_tw(const WArgs& A, int tw, int tm, hipStream_t st) {
 extern "C" int vg_debug_set_wgrad(int what, int value) {
   if (what == 0) g_wgrad_tm_override = value;
   else if (what == 1) g_wgrad_blocks_target = value;
+  else if (what == 2) g_wgrad_ks = value;
   else return VG_ERR_BAD_ARG;
   return 0;
 }

@@ -42,57 +42,70 @@ class ModelOpt:
 
 
 class FlatGrads:
-    """All gradients of a network as views into one contiguous fp32 buffer, exchanged with
-    bucketed RCCL all-reduces (SUM) that overlap the rest of the backward pass.
+    """Gradient exchange of one network for data parallelism: RCCL all-reduces (SUM) launched from
+    autograd hooks so that they overlap the rest of the backward pass.
 
-    The buffer follows parameter order; buckets are contiguous slices of ~`bucket_bytes`, cut
-    from the END of the parameter list (the layers whose gradients autograd finishes first).
-    A post-accumulate-grad hook counts a bucket's parameters down; when the last one is ready the
-    bucket's all-reduce is enqueued asynchronously (it runs on RCCL's stream, ordered after the
-    kernels that produced those gradients).  `finish()` reduces whatever did not fire and waits.
-    xGMI is point-to-point (7 links x ~153 GB/s per GPU): a few large buckets keep every ring /
-    tree RCCL builds busy, and the 134 MB Linear-weight buckets -- ready first in backward -- hide
-    behind the convolution backward."""
+    * LARGE parameters (>= `direct_bytes`; the 134 MB Linear weights and the big conv filters,
+      > 95 % of the payload) are reduced IN PLACE on the gradient tensor autograd produced, as
+      soon as it is final -- no flattening copy, no zero-fill, no extra accumulate pass.  The
+      Linear-weight gradients are the first ones ready in backward, so their exchange hides
+      behind the convolution backward.
+    * SMALL parameters live as views in one flat fp32 buffer, cut into buckets of ~`bucket_bytes`
+      from the END of the parameter list (ready first); a bucket is reduced when its last
+      gradient has been accumulated.
+    `finish()` reduces whatever did not fire and makes the compute stream wait for every
+    exchange.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): few, large messages keep
+    all the rings / trees RCCL builds busy."""
 
-    def __init__(self, params, bucket_bytes=96 << 20, overlap=True):
+    def __init__(self, params, bucket_bytes=8 << 20, direct_bytes=1 << 20, overlap=True):
         self.params = [p for p in params]
-        n = sum(p.numel() for p in self.params)
+        self.direct = [p.numel() * 4 >= direct_bytes for p in self.params]
+        small = [i for i, d in enumerate(self.direct) if not d]
+        n = sum(self.params[i].numel() for i in small)
         dev = self.params[0].device
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.views, self.offsets = [], []
+        self.flat = torch.zeros(max(n, 1), dtype=torch.float32, device=dev)
+        self.views, self.offsets = {}, {}
         off = 0
-        for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
-            self.offsets.append(off)
+        for i in small:
+            p = self.params[i]
+            self.views[i] = self.flat[off:off + p.numel()].view_as(p)
+            self.offsets[i] = off
             off += p.numel()
-        # buckets from the last parameter backwards
-        self.buckets = []          # dicts: start, end (element offsets), members (param indices)
+        self.buckets = []          # dicts: start, end (element offsets into flat), members (param indices)
         cap = max(1, bucket_bytes // 4)
         cur = None
-        for i in reversed(range(len(self.params))):
-            if cur is None or (cur["end"] - self.offsets[i]) > cap and cur["members"]:
+        for i in reversed(small):
+            if cur is None or ((cur["end"] - self.offsets[i]) > cap and cur["members"]):
                 cur = dict(start=self.offsets[i], end=self.offsets[i] + self.params[i].numel(), members=[])
                 self.buckets.append(cur)
             cur["start"] = self.offsets[i]
             cur["members"].append(i)
-        self.bucket_of = {}
-        for b_i, b in enumerate(self.buckets):
-            for i in b["members"]:
-                self.bucket_of[i] = b_i
+        self.bucket_of = {i: b_i for b_i, b in enumerate(self.buckets) for i in b["members"]}
         self.overlap = overlap
-        self._pending, self._launched, self._handles = [], [], []
+        self._pending, self._launched, self._direct_done, self._handles = [], [], set(), []
         self._armed = False
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
 
     def _make_hook(self, i):
-        def hook(_p):
+        def hook(p):
             if not self._armed:
+                return
+            if self.direct[i]:
+                if self.overlap:
+                    self._reduce_direct(i)
                 return
             b = self.bucket_of[i]
             self._pending[b] -= 1
             if self._pending[b] == 0 and self.overlap:
                 self._launch(b)
         return hook
+
+    def _reduce_direct(self, i):
+        g = self.params[i].grad
+        if g is None or i in self._direct_done:
+            return
+        self._direct_done.add(i)
+        self._handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
 
     def _launch(self, b):
         bk = self.buckets[b]
@@ -101,19 +114,25 @@ class FlatGrads:
                                              async_op=True))
 
     def zero_and_attach(self):
+        """Start of a phase: small gradients -> zeroed views of the flat buffer (autograd
+        accumulates into them in place); large gradients -> None (autograd installs its result)."""
         self.flat.zero_()
-        for p, v in zip(self.params, self.views):
-            p.grad = v
+        for i, p in enumerate(self.params):
+            p.grad = None if self.direct[i] else self.views[i]
         self._pending = [len(b["members"]) for b in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._direct_done = set()
         self._handles = []
         self._armed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
     def finish(self):
-        """Reduce the buckets whose hooks did not all fire (or all of them without overlap), then
-        make the current stream wait for every exchange."""
+        """Reduce what did not fire from the hooks (or everything, without overlap), then make
+        the current stream wait for every exchange."""
         if not self._armed:
             return
+        for i, d in enumerate(self.direct):
+            if d:
+                self._reduce_direct(i)
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)
@@ -122,9 +141,10 @@ class FlatGrads:
         self._handles = []
         self._armed = False
 
-    def all_reduce(self, group=None):
-        """Single synchronous all-reduce of the whole buffer (no bucketing)."""
-        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+    def gathered(self):
+        """All gradients flattened in parameter order (tests / diagnostics; copies)."""
+        return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                          for p in self.params])
 
 
 def _make_adam(params, lr, fused):

@@ -19,9 +19,15 @@ for name, cin, cout, h, s in L:
     gy = torch.randn(B, cout, h // s, h // s, device="cuda")
     gf = 2.0 * B * (h // s) ** 2 * cin * cout * 25 / 1e9
     res = []
-    for tm in (128, 64):
-        for tgt in (512, 1024, 2048):
-            lib.vg_debug_set_wgrad(0, tm); lib.vg_debug_set_wgrad(1, tgt)
+    ref = None
+    for ks in (1, 2):
+        for tgt in (-1, 1024, 2048):
+            lib.vg_debug_set_wgrad(2, ks); lib.vg_debug_set_wgrad(1, tgt)
+            out = ops.conv5x5_wgrad(x, gy, s)
+            if ref is None:
+                ref = out.clone()
+            err = float((out - ref).abs().max() / ref.abs().max())
             ms = timeit(lambda: ops.conv5x5_wgrad(x, gy, s))
-            res.append(f"tm{tm}/b{tgt}:{ms*1e3:5.0f}us {gf/ms:5.1f}TF")
+            res.append(f"ks{ks}/b{tgt}:{ms*1e3:5.0f}us {gf/ms:5.1f}TF e{err:.0e}")
+    lib.vg_debug_set_wgrad(2, 2); lib.vg_debug_set_wgrad(1, -1)
     print(f"{name:7s} {gf:5.1f}GF " + " ".join(res), flush=True)

@@ -86,11 +86,14 @@ def _dp_worker(rank, world, port, batch, q):
     d, g = _replica_grads(rank, world, batch, None)
     flat = FlatGrads(d.parameters())
     flat.zero_and_attach()
-    for p, gi in zip(d.parameters(), g):
-        p.grad.add_(gi)                      # what autograd's accumulation does in the trainer
+    for p, gi in zip(d.parameters(), g):     # what autograd's AccumulateGrad does in the trainer:
+        if p.grad is None:
+            p.grad = gi.clone()              # large tensors: the produced gradient is installed
+        else:
+            p.grad.add_(gi)                  # small tensors: accumulated into the flat views
     flat.finish()                            # no hook fired (no backward here): every bucket reduced now
     if rank == 0:
-        q.put(flat.flat.clone())
+        q.put(flat.gathered())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -127,17 +130,17 @@ def _bucket_worker(rank, world, port, q):
                               torch.nn.Linear(64, 8))
     unused = torch.nn.Parameter(torch.zeros(5))            # never receives a gradient: finish() must cover it
     params = list(net.parameters()) + [unused]
-    flat = FlatGrads(params, bucket_bytes=4096 * 4, overlap=True)
-    assert len(flat.buckets) >= 3
+    flat = FlatGrads(params, bucket_bytes=512 * 4, direct_bytes=64 * 64 * 4, overlap=True)
+    assert len(flat.buckets) >= 2 and sum(flat.direct) == 1      # the 64x64 weight goes direct
     res = []
     for it in range(2):                                    # two phases reuse the same buffers
         flat.zero_and_attach()
         g = torch.Generator().manual_seed(100 * it + rank)
         x = torch.randn(16, 40, generator=g)
         net(x).pow(2).sum().backward()
-        fired_early = sum(flat._launched)
+        fired_early = sum(flat._launched) + len(flat._direct_done)
         flat.finish()
-        res.append((flat.flat.clone(), fired_early))
+        res.append((flat.gathered(), fired_early))
     if rank == 0:
         q.put(res)
     dist.barrier()
