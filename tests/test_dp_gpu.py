@@ -15,7 +15,7 @@ from conftest import BN_SHADOWED
 
 pytestmark = pytest.mark.gpu
 
-WORLD, BATCH = 2, 8
+WORLD, BATCH = 2, 32
 
 
 def _free_port():
@@ -42,7 +42,7 @@ def _worker(rank, port, q):
                       grad_hook=lambda ph, net: got.__setitem__(
                           ph, {k: p.grad.detach().cpu().double() for k, p in net.named_parameters()}))
         torch.cuda.synchronize()
-        worst = 0.0
+        worst, worst_k = 0.0, ""
         if rank == 0:
             torch.set_num_threads(8)
             ref = {}
@@ -64,7 +64,8 @@ def _worker(rank, port, q):
                     if k in BN_SHADOWED[key] or float(r_.norm()) == 0.0:
                         continue
                     e = float((got[ph][k] - r_).norm() / r_.norm())
-                    worst = max(worst, e)
+                    if e > worst:
+                        worst, worst_k = e, f"{ph}/{k}"
         # replicas stay in lock-step: same (reduced) gradients on both ranks
         g0 = got["EG3"]["deconv2.weight"].float().cuda()
         g1 = g0.clone()
@@ -72,7 +73,7 @@ def _worker(rank, port, q):
         lock = float((g0 - g1).abs().max())
         dist.barrier()
         if rank == 0:
-            q.put(("ok", worst, lock))
+            q.put(("ok", (worst, worst_k), lock))
         elif lock != 0.0:
             q.put(("lockstep", lock, 0.0))
         dist.destroy_process_group()
@@ -94,6 +95,7 @@ def test_two_rank_step_matches_two_replica_oracle():
     assert status == "ok", (status, worst)
     assert all(p.exitcode == 0 for p in procs)
     assert lock == 0.0
-    # 3e-3: one ReLU unit on the other side of zero (see test_step_gpu); a wrong divisor, a
-    # missing rank or a mean-instead-of-sum reduction would be off by O(1)
-    assert worst <= 3e-3, worst
+    # 1e-2 relative L2 per tensor at a local batch of 16: one ReLU unit on the other side of zero
+    # moves a gradient by ~1/sqrt(#units of its layer) (a BatchNorm1d layer has only 16 x 2048
+    # units here); a wrong divisor, a missing rank or a mean-instead-of-sum reduction is O(1)
+    assert worst[0] <= 1e-2, worst
