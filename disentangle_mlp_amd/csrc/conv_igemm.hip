@@ -112,8 +112,12 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
   const int iw0 = (MODE == MODE_FWD) ? tw0 * S - 2 : tw0 - (NTMAX - 1 - 2 / S);
   const float* xb = A.x + (size_t)b0 * Cin * HW;
 
-  // ---- per-thread patch staging map (invariant over the K loop)
+  // ---- per-thread patch staging map (invariant over the K loop).  Every load address is
+  // CLAMPED into the tensor (distinct, always valid) instead of being predicated: the prefetch
+  // is straight-line code with no dependent or merged loads; halo / tail elements are replaced
+  // by 0 when the registers are written to LDS.
   int pofs[NQP];
+  unsigned pvalid = 0;   // bit q: spatially inside the image (and a real image)
 #pragma unroll
   for (int q = 0; q < NQP; ++q) {
     const int e = tid + q * NT;
@@ -121,11 +125,14 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
     int t = e / PWP;
     const int r = t % PH;
     t /= PH;
-    const int c = t % CK, nb = t / CK;
+    const int nb = t / CK;
     const int ih = ih0 + r, iw = iw0 + col;
     const bool ok = (e < NP) && (col < PW) && ih >= 0 && ih < XH && iw >= 0 && iw < XW && (b0 + nb) < A.B;
-    pofs[q] = ok ? (nb * Cin + c) * HW + ih * XW + iw : -1;
+    const int nbc = min(nb, A.B - 1 - b0), ihc = min(max(ih, 0), XH - 1), iwc = min(max(iw, 0), XW - 1);
+    pofs[q] = nbc * Cin * HW + ihc * XW + iwc;
+    pvalid |= ok ? (1u << q) : 0u;
   }
+  static_assert(NQP <= 32, "patch validity mask is 32-bit");
 
   // ---- filter staging map: RL consecutive lanes stage one filter row
   const int w_sub = tid / RL, w_r = tid % RL;
@@ -134,29 +141,23 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
   const int w_kh = (MODE == MODE_FWD) ? w_t / 5 : R + S * (w_t / NTW);
   const int w_kw = (MODE == MODE_FWD) ? w_t % 5 : SS + S * (w_t % NTW);
   // conv weight [Cout][Cin][25]; transposed-conv weight [Cin][Cout][25]
-  const size_t w_row_stride = (MODE == MODE_FWD) ? (size_t)Cin * 25 : 25;
-  const size_t w_ch_stride = (MODE == MODE_FWD) ? 25 : (size_t)Cout * 25;
-  const float* wsrc = A.w + (size_t)(n0 + w_sub) * w_row_stride + w_c * w_ch_stride + w_kh * 5 + w_kw;
+  const int w_row_stride = (MODE == MODE_FWD) ? Cin * 25 : 25;
+  const int w_ch_stride = (MODE == MODE_FWD) ? 25 : Cout * 25;
+  const int w_tap = w_kh * 5 + w_kw;
 
   float preg[NQP], wreg[NQW];
-  // Branch-free staging: an out-of-range element loads from offset 0 (always mapped); it is
-  // replaced by 0 only when the registers are written to LDS (after the MFMAs of the current
-  // chunk), so the loads stay in flight under the compute loop.
   auto load_chunk = [&](int c0) {
 #pragma unroll
     for (int q = 0; q < NQP; ++q) {
       const int e = tid + q * NT;
       const int c = (e / (PWP * PH)) % CK;
-      const bool ok = pofs[q] >= 0 && (c0 + c) < Cin;
-      preg[q] = xb[ok ? pofs[q] + c0 * HW : 0];
+      preg[q] = xb[pofs[q] + min(c0 + c, Cin - 1) * HW];
     }
-    const bool cok = wrow_ok && (c0 + w_c) < Cin;
-    const float* wp_ = cok ? wsrc + c0 * w_ch_stride : A.w;
+    const int wbase = min(c0 + w_c, Cin - 1) * w_ch_stride + w_tap;
 #pragma unroll
     for (int q = 0; q < NQW; ++q) {
-      const int co_l = w_sub + q * RP;
-      const bool ok = cok && co_l < TN && (n0 + co_l) < Cout;
-      wreg[q] = wp_[ok ? (size_t)q * RP * w_row_stride : 0];
+      const int row = min(n0 + w_sub + q * RP, Cout - 1);
+      wreg[q] = A.w[row * w_row_stride + wbase];
     }
   };
   auto store_chunk = [&](float* st, int c0) {
@@ -165,7 +166,7 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
     for (int q = 0; q < NQP; ++q) {
       const int e = tid + q * NT;
       const int c = (e / (PWP * PH)) % CK;
-      const bool ok = pofs[q] >= 0 && (c0 + c) < Cin;
+      const bool ok = ((pvalid >> q) & 1u) && (c0 + c) < Cin;
       st[(e < NP) ? e : DUMMY] = ok ? preg[q] : 0.f;
     }
     const bool cok = wrow_ok && (c0 + w_c) < Cin;
@@ -288,13 +289,16 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
     float* yb = A.y + ((size_t)b * Cout * YH + oh) * YW + ow;
 #pragma unroll
     for (int g = 0; g < FC; ++g) {
+      float bv[16];
+#pragma unroll
+      for (int r16 = 0; r16 < 16; ++r16) {   // one batch of loads (clamped rows), one wait
+        const int co = min(n0 + (wc * FC + g) * 32 + acc_row(r16, lane), Cout - 1);
+        bv[r16] = A.bias ? A.bias[co] : 0.f;
+      }
 #pragma unroll
       for (int r16 = 0; r16 < 16; ++r16) {
         const int co = n0 + (wc * FC + g) * 32 + acc_row(r16, lane);
-        if (pok && co < Cout) {
-          const float bv = A.bias ? A.bias[co] : 0.f;
-          yb[(size_t)co * YH * YW] = acc[g][f][r16] + bv;
-        }
+        if (pok && co < Cout) yb[(size_t)co * YH * YW] = acc[g][f][r16] + bv[r16];
       }
     }
   }
