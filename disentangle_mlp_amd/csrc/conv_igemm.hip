@@ -354,7 +354,7 @@ int launch(const float* x, const float* w, const float* bias, float* y, int B, i
 //   variant 0: 128 px x 128 cout, CK 2 (fwd) / 4 (tr)     variant 3: 128 px x 64 cout, CK 2 / 4
 //   variant 1: variant 5 + raised MFMA-phase priority     variant 4: 64 px x 64 cout, 8 waves (K split 2)
 //   variant 2: 64 px x 64 cout                            variant 5: 128 px x 64 cout, 8 waves (K split 2)
-//   variant 6: 128 px x 32 cout (thin outputs), 4 waves along the pixels
+//   variant 6: 128 px x 32 cout (thin outputs), 4 waves    variant 7: 256 px x 32 cout, 8 waves
 template <int MODE, int S, int WIDTH, int VAR>
 struct Pick;
 #define VG_PICK(WIDTH, VAR, NB, TH, TW, TN, WC, WP, CKF, CKT, PIPE, KS)                                         \
@@ -366,26 +366,30 @@ struct Pick;
 VG_PICK(32, 0, 1, 4, 32, 128, 2, 2, 2, 4, 0, 1)
 VG_PICK(16, 0, 1, 8, 16, 128, 2, 2, 2, 4, 0, 1)
 VG_PICK(8, 0, 2, 8, 8, 128, 2, 2, 2, 4, 0, 1)
-VG_PICK(32, 1, 1, 4, 32, 64, 2, 2, 4, 8, 2, 2)
-VG_PICK(16, 1, 1, 8, 16, 64, 2, 2, 4, 8, 2, 2)
-VG_PICK(8, 1, 2, 8, 8, 64, 2, 2, 4, 8, 2, 2)
+VG_PICK(32, 1, 1, 8, 32, 64, 2, 4, 2, 4, 0, 1)
+VG_PICK(16, 1, 1, 16, 16, 64, 2, 4, 2, 4, 0, 1)
+VG_PICK(8, 1, 4, 8, 8, 64, 2, 4, 2, 4, 0, 1)
 VG_PICK(32, 2, 1, 2, 32, 64, 2, 2, 2, 4, 0, 1)
 VG_PICK(16, 2, 1, 4, 16, 64, 2, 2, 2, 4, 0, 1)
 VG_PICK(8, 2, 1, 8, 8, 64, 2, 2, 2, 4, 0, 1)
 VG_PICK(32, 3, 1, 4, 32, 64, 2, 2, 2, 4, 0, 1)
 VG_PICK(16, 3, 1, 8, 16, 64, 2, 2, 2, 4, 0, 1)
 VG_PICK(8, 3, 2, 8, 8, 64, 2, 2, 2, 4, 0, 1)
-VG_PICK(32, 4, 1, 2, 32, 64, 2, 2, 4, 8, 0, 2)
-VG_PICK(16, 4, 1, 4, 16, 64, 2, 2, 4, 8, 0, 2)
-VG_PICK(8, 4, 1, 8, 8, 64, 2, 2, 4, 8, 0, 2)
+VG_PICK(32, 4, 1, 8, 32, 128, 2, 4, 2, 4, 0, 1)
+VG_PICK(16, 4, 1, 16, 16, 128, 2, 4, 2, 4, 0, 1)
+VG_PICK(8, 4, 4, 8, 8, 128, 2, 4, 2, 4, 0, 1)
 VG_PICK(32, 5, 1, 4, 32, 64, 2, 2, 4, 8, 0, 2)
 VG_PICK(16, 5, 1, 8, 16, 64, 2, 2, 4, 8, 0, 2)
 VG_PICK(8, 5, 2, 8, 8, 64, 2, 2, 4, 8, 0, 2)
 VG_PICK(32, 6, 1, 4, 32, 32, 1, 4, 2, 4, 0, 1)
 VG_PICK(16, 6, 1, 8, 16, 32, 1, 4, 2, 4, 0, 1)
 VG_PICK(8, 6, 2, 8, 8, 32, 1, 4, 2, 4, 0, 1)
+// thin outputs, 256 px x 32 cout, 8 waves along the pixels
+VG_PICK(32, 7, 1, 8, 32, 32, 1, 8, 2, 4, 0, 1)
+VG_PICK(16, 7, 1, 16, 16, 32, 1, 8, 2, 4, 0, 1)
+VG_PICK(8, 7, 4, 8, 8, 32, 1, 8, 2, 4, 0, 1)
 #undef VG_PICK
-constexpr int NVAR = 7;
+constexpr int NVAR = 8;
 
 int g_tile_override[2] = {-1, -1};  // diagnostics only (vg_debug_set_conv_tile)
 
@@ -399,7 +403,8 @@ int launch_var(int var, const float* x, const float* w, const float* bias, float
     case 3: return launch<typename Pick<MODE, S, WIDTH, 3>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
     case 4: return launch<typename Pick<MODE, S, WIDTH, 4>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
     case 5: return launch<typename Pick<MODE, S, WIDTH, 5>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    default: return launch<typename Pick<MODE, S, WIDTH, 6>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    case 6: return launch<typename Pick<MODE, S, WIDTH, 6>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    default: return launch<typename Pick<MODE, S, WIDTH, 7>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
   }
 }
 
@@ -411,18 +416,22 @@ int dispatch(const float* x, const float* w, const float* bias, float* y, int B,
   const int tsw = (MODE == MODE_FWD) ? (XW - 1) / S + 1 : XW;
   const int tsh = (MODE == MODE_FWD) ? (XH - 1) / S + 1 : XH;
   const int width = tsw >= 32 ? 32 : (tsw >= 16 ? 16 : 8);
-  // Measured on MI355X at B=128 (scripts/tune_conv.py): the 128 px x 64 cout tile wins or ties on
-  // every heavy layer.  The 8-wave form (in-workgroup split of the K chunk) doubles the resident
-  // waves per tile: it wins for the forward kernel everywhere and for the transposed kernel when
-  // the 4-wave grid would leave SIMDs with a single wave (< 768 workgroups).
+  // Measured on MI355X at B=128 (scripts/tune_conv.py).  Staging (global loads -> LDS) is the
+  // cost next to the MFMAs, so the biggest pixel tile that still fills the chip wins: 256 px x
+  // 128 / 64 cout (8 waves) on the large grids, 128 px x 64 cout otherwise -- with 8 waves
+  // (in-workgroup split of the K chunk) where 4 waves would leave SIMDs with a single wave.
+  const long px256 = (long)cdiv(B * cdiv(tsh, 8) * cdiv(tsw, 8) * 64, 256);
+  const int ncls = (MODE == MODE_TR) ? S * S : 1;
   int var;
   if (Cout <= 32) {
-    var = 6;
+    var = (px256 * ncls >= 2048) ? 7 : 6;
   } else if (MODE == MODE_FWD) {
-    var = 5;
+    if (px256 * cdiv(Cout, 128) >= 256 && Cout > 64) var = 4;
+    else if (px256 * cdiv(Cout, 64) >= 256) var = 1;
+    else var = 5;
   } else {
-    const long blocks = (long)cdiv(B * cdiv(tsh, 8) * cdiv(tsw, 8) * 64, 128) * cdiv(Cout, 64) * S * S;
-    var = blocks < 768 ? 5 : 3;
+    if (px256 * cdiv(Cout, 64) * ncls >= 1024) var = 1;
+    else var = (2 * px256 * cdiv(Cout, 64) * ncls < 768) ? 5 : 3;
   }
   const int ov = g_tile_override[MODE];
   const int use = (ov >= 0 && ov < NVAR) ? ov : var;

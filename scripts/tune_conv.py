@@ -49,3 +49,14 @@ for name, cin, cout, h in TR:
         res.append(f"v{v}:{ms*1e3:6.0f}us {gf/ms:5.1f}TF")
     lib.vg_debug_set_conv_tile(1, -1)
     print(f"TR  {name:9s} {gf:5.1f}GF  " + "  ".join(res), flush=True)
+for name, cin, cout, h in THIN:
+    x = torch.randn(B, cin, h, h, device="cuda")
+    w = torch.randn(cin, cout, 5, 5, device="cuda") * 0.02
+    gf = 2.0 * B * h * h * cin * cout * 25 / 1e9
+    res = []
+    for v in (6, 7, -1):
+        lib.vg_debug_set_conv_tile(1, v)
+        ms = timeit(lambda: ops.convT5x5_fwd(x, w, None, 2))
+        res.append(f"v{v}:{ms*1e3:6.0f}us {gf/ms:5.1f}TF")
+    lib.vg_debug_set_conv_tile(1, -1)
+    print(f"TR  {name:9s} {gf:5.1f}GF  " + "  ".join(res), flush=True)
