@@ -21,15 +21,17 @@
 namespace {
 
 constexpr int WG_NT = 256;
-constexpr int CIT = 5;    // input channels per column tile (125 of 128 columns used)
 constexpr int KC = 64;    // output pixels per K chunk
 
-template <int S_, int TW_, int TM_, int KS_ = 1>
+// CIT input channels per column tile: 5 -> 125 of 128 MFMA columns, 10 -> 250 of 256 (the gy tile is
+// then staged half as often per FLOP; 8 waves as 2 x 4 instead of 2 x 2 x 2 K groups)
+template <int S_, int TW_, int TM_, int KS_ = 1, int CIT_ = 5>
 struct WCfg {
-  static constexpr int S = S_, TW = TW_, TH = KC / TW_, TM = TM_, KS = KS_;
-  static constexpr int NT = WG_NT * KS;   // KS wave groups split the 64-pixel K chunk
-  static constexpr int WM = (TM >= 64) ? 2 : 1, WN = 4 / WM;
-  static constexpr int FC = TM / 32 / WM, FN = 128 / 32 / WN;
+  static constexpr int S = S_, TW = TW_, TH = KC / TW_, TM = TM_, KS = KS_, CIT = CIT_;
+  static constexpr int TNP = (CIT * 25 + 31) / 32 * 32;   // padded column tile
+  static constexpr int WM = (TM >= 64) ? 2 : 1, WN = (TNP / 128) * (4 / WM);
+  static constexpr int NT = 64 * WM * WN * KS;   // KS wave groups split the 64-pixel K chunk
+  static constexpr int FC = TM / 32 / WM, FN = TNP / 32 / WN;
   static constexpr int PH = S * (TH - 1) + 5, PW = S * (TW - 1) + 5, PWP = PW | 1;
   static constexpr int NPATCH = CIT * PH * PWP;
   static constexpr int AS = KC + 1;
@@ -57,7 +59,8 @@ __global__ __launch_bounds__(C::NT, 2) void conv5x5_wgrad_kernel(WArgs A) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int h = lane >> 5, l32 = lane & 31;
-  const int kg = wid / 4, w4 = wid % 4;   // K group, wave within the output tile
+  constexpr int CIT = C::CIT, WPT = C::WM * C::WN;
+  const int kg = wid / WPT, w4 = wid % WPT;   // K group, wave within the output tile
   const int wm = w4 % C::WM, wn = w4 / C::WM;
   constexpr int NT = C::NT, NWV = C::NT / 64;
   int bid = blockIdx.x;
@@ -227,10 +230,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 struct Plan {
-  int tw, tm, mtiles, ntiles, splits, tiles_w, tiles_hw, chunks, cps, OH, OW;
+  int tw, tm, cit, mtiles, ntiles, splits, tiles_w, tiles_hw, chunks, cps, OH, OW;
 };
 
 int g_wgrad_ks = 2;                 // 8-wave K-split kernel for the 128-row tile (1 = 4-wave form, diagnostics)
+int g_wgrad_cit = 5;                // 10 = 250-column tile for the 128-row tile (measured slower: diagnostics)
 int g_wgrad_tm_override = -1;       // diagnostics only (vg_debug_set_conv_tile mode 2)
 int g_wgrad_blocks_target = -1;     // diagnostics only
 
@@ -243,7 +247,8 @@ Plan make_plan(int B, int Cin, int H, int W, int Cout, int S) {
   if (p.tm == 128 && Cout <= 128 && Cin <= 32) p.tm = 64;   // few column tiles: more row tiles instead
   if (g_wgrad_tm_override > 0 && g_wgrad_tm_override <= p.tm) p.tm = g_wgrad_tm_override;
   p.mtiles = cdiv(Cout, p.tm);
-  p.ntiles = cdiv(Cin, CIT);
+  p.cit = (g_wgrad_cit == 10 && p.tm == 128 && Cin >= 20) ? 10 : 5;
+  p.ntiles = cdiv(Cin, p.cit);
   const int th = KC / p.tw;
   p.tiles_w = cdiv(p.OW, p.tw);
   p.tiles_hw = p.tiles_w * cdiv(p.OH, th);
@@ -269,19 +274,20 @@ int launch_w(const WArgs& A, hipStream_t st) {
 }
 
 template <int S, int TW>
-int dispatch_tm(const WArgs& A, int tm, hipStream_t st) {
+int dispatch_tm(const WArgs& A, int tm, int cit, hipStream_t st) {
+  if (tm == 128 && cit == 10) return launch_w<WCfg<S, TW, 128, 1, 10>>(A, st);
   if (tm == 128) return g_wgrad_ks == 2 ? launch_w<WCfg<S, TW, 128, 2>>(A, st) : launch_w<WCfg<S, TW, 128>>(A, st);
   if (tm == 64) return launch_w<WCfg<S, TW, 64>>(A, st);
   return launch_w<WCfg<S, TW, 32>>(A, st);
 }
 
 template <int S>
-int dispatch_tw(const WArgs& A, int tw, int tm, hipStream_t st) {
+int dispatch_tw(const WArgs& A, int tw, int tm, int cit, hipStream_t st) {
   switch (tw) {
-    case 8: return dispatch_tm<S, 8>(A, tm, st);
-    case 16: return dispatch_tm<S, 16>(A, tm, st);
-    case 32: return dispatch_tm<S, 32>(A, tm, st);
-    default: return dispatch_tm<S, 64>(A, tm, st);
+    case 8: return dispatch_tm<S, 8>(A, tm, cit, st);
+    case 16: return dispatch_tm<S, 16>(A, tm, cit, st);
+    case 32: return dispatch_tm<S, 32>(A, tm, cit, st);
+    default: return dispatch_tm<S, 64>(A, tm, cit, st);
   }
 }
 
@@ -291,6 +297,7 @@ extern "C" int vg_debug_set_wgrad(int what, int value) {
   if (what == 0) g_wgrad_tm_override = value;
   else if (what == 1) g_wgrad_blocks_target = value;
   else if (what == 2) g_wgrad_ks = value;
+  else if (what == 3) g_wgrad_cit = value;
   else return VG_ERR_BAD_ARG;
   return 0;
 }
@@ -314,7 +321,7 @@ extern "C" int vg_conv5x5_wgrad(const float* x, const float* gy, float* dw, int 
   A.B = B; A.Cin = Cin; A.H = H; A.W = W; A.Cout = Cout; A.OH = p.OH; A.OW = p.OW;
   A.mtiles = p.mtiles; A.ntiles = p.ntiles; A.splits = p.splits;
   A.tiles_w = p.tiles_w; A.tiles_hw = p.tiles_hw; A.chunks = p.chunks; A.chunks_per_split = p.cps;
-  int rc = (stride == 2) ? dispatch_tw<2>(A, p.tw, p.tm, st) : dispatch_tw<1>(A, p.tw, p.tm, st);
+  int rc = (stride == 2) ? dispatch_tw<2>(A, p.tw, p.tm, p.cit, st) : dispatch_tw<1>(A, p.tw, p.tm, p.cit, st);
   if (rc) return rc;
   const int n = Cout * Cin * 25;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, (const float*)workspace, dw, n,
