@@ -30,11 +30,10 @@ namespace {
 
 enum { MODE_FWD = 0, MODE_TR = 1 };
 
-template <int MODE_, int S_, int NB_, int TH_, int TW_, int TN_, int WC_, int WP_, int CK_, int MINW_ = 2, int PIPE_ = 0,
-          int KS_ = 1>
+template <int MODE_, int S_, int NB_, int TH_, int TW_, int TN_, int WC_, int WP_, int CK_, int MINW_ = 2, int KS_ = 1>
 struct Cfg {
   static constexpr int MODE = MODE_, S = S_, NB = NB_, TH = TH_, TW = TW_, TN = TN_, WC = WC_, WP = WP_,
-                       CK = CK_, MINW = MINW_, PIPE = PIPE_, KS = KS_;  // KS: in-workgroup split of the K chunk
+                       CK = CK_, MINW = MINW_, KS = KS_;  // KS: in-workgroup split of the K chunk
   static constexpr int NT = 64 * WC * WP * KS;
   static constexpr int TM = NB * TH * TW;
   static constexpr int FC = TN / 32 / WC;  // 32-row cout fragments per wave
@@ -207,9 +206,9 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
     const float* st = smem + (ch & 1) * C::STAGE;
     const bool more = (ch + 1) < nchunks;
     if (more) load_chunk((ch + 1) * CK);
-    // (cp, tap) steps, operands of step t+1 read from LDS before the MFMAs of step t issue
+    // (cp, tap) steps of this K group; the compiler interleaves the LDS reads with the MFMAs
     constexpr int NSTEP = CPG * NTAP;
-    float a_cur[FC], b_cur[FP], a_nxt[FC], b_nxt[FP];
+    float a_cur[FC], b_cur[FP];
     auto read_step = [&](int stp, float* a, float* b) {
       const int cp = stp / NTAP, t = stp % NTAP;
       const int ro = (MODE == MODE_FWD) ? t / 5 : NTMAX - 1 - t / NTW;   // patch row / col offset of the tap
@@ -219,34 +218,14 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
 #pragma unroll
       for (int f = 0; f < FP; ++f) b[f] = st[base_p[f] + (2 * cp * PH + ro) * PWP + cof];
     };
-    if constexpr (C::PIPE == 2) __builtin_amdgcn_s_setprio(2);
-    if constexpr (C::PIPE == 1) {
-      read_step(0, a_cur, b_cur);
 #pragma unroll
-      for (int stp = 0; stp < NSTEP; ++stp) {
-        if (stp + 1 < NSTEP) read_step(stp + 1, a_nxt, b_nxt);
-        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this step's MFMAs
+    for (int stp = 0; stp < NSTEP; ++stp) {
+      read_step(stp, a_cur, b_cur);
 #pragma unroll
-        for (int g = 0; g < FC; ++g)
+      for (int g = 0; g < FC; ++g)
 #pragma unroll
-          for (int f = 0; f < FP; ++f) acc[g][f] = mfma32(a_cur[g], b_cur[f], acc[g][f]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < FC; ++g) a_cur[g] = a_nxt[g];
-#pragma unroll
-        for (int f = 0; f < FP; ++f) b_cur[f] = b_nxt[f];
-      }
-    } else {
-#pragma unroll
-      for (int stp = 0; stp < NSTEP; ++stp) {
-        read_step(stp, a_cur, b_cur);
-#pragma unroll
-        for (int g = 0; g < FC; ++g)
-#pragma unroll
-          for (int f = 0; f < FP; ++f) acc[g][f] = mfma32(a_cur[g], b_cur[f], acc[g][f]);
-      }
+        for (int f = 0; f < FP; ++f) acc[g][f] = mfma32(a_cur[g], b_cur[f], acc[g][f]);
     }
-    if constexpr (C::PIPE == 2) __builtin_amdgcn_s_setprio(0);
     if (more) store_chunk(smem + ((ch + 1) & 1) * C::STAGE, (ch + 1) * CK);
     __syncthreads();
   }
@@ -351,43 +330,44 @@ int launch(const float* x, const float* w, const float* bias, float* y, int B, i
 
 // ---- tile variants ------------------------------------------------------------------
 // Geometry by tile-space width: W32 -> rows of 32 pixels, W16 -> 16, W8 -> 8x8 images.
-//   variant 0: 128 px x 128 cout, CK 2 (fwd) / 4 (tr)     variant 3: 128 px x 64 cout, CK 2 / 4
-//   variant 1: variant 5 + raised MFMA-phase priority     variant 4: 64 px x 64 cout, 8 waves (K split 2)
-//   variant 2: 64 px x 64 cout                            variant 5: 128 px x 64 cout, 8 waves (K split 2)
-//   variant 6: 128 px x 32 cout (thin outputs), 4 waves    variant 7: 256 px x 32 cout, 8 waves
+//   variant 0: 128 px x 128 cout, 4 waves              variant 4: 256 px x 128 cout, 8 waves
+//   variant 1: 256 px x  64 cout, 8 waves              variant 5: 128 px x 64 cout, 8 waves (K split 2)
+//   variant 2:  64 px x  64 cout, 4 waves              variant 6: 128 px x 32 cout, 4 waves (thin)
+//   variant 3: 128 px x  64 cout, 4 waves              variant 7: 256 px x 32 cout, 8 waves (thin)
+// K chunk: 2 channels (forward / stride 1) or 4 (stride-2 transposed); 4 / 8 for the K-split form.
 template <int MODE, int S, int WIDTH, int VAR>
 struct Pick;
-#define VG_PICK(WIDTH, VAR, NB, TH, TW, TN, WC, WP, CKF, CKT, PIPE, KS)                                         \
+#define VG_PICK(WIDTH, VAR, NB, TH, TW, TN, WC, WP, CKF, CKT, KS)                                         \
   template <int MODE, int S>                                                                              \
   struct Pick<MODE, S, WIDTH, VAR> {                                                                      \
-    using type = Cfg<MODE, S, NB, TH, TW, TN, WC, WP, ((MODE == MODE_FWD || S == 1) ? CKF : CKT), 2, PIPE, KS>; \
+    using type = Cfg<MODE, S, NB, TH, TW, TN, WC, WP, ((MODE == MODE_FWD || S == 1) ? CKF : CKT), 2, KS>; \
   };
-//       W  V NB TH TW   TN WC WP CKF CKT PIPE KS
-VG_PICK(32, 0, 1, 4, 32, 128, 2, 2, 2, 4, 0, 1)
-VG_PICK(16, 0, 1, 8, 16, 128, 2, 2, 2, 4, 0, 1)
-VG_PICK(8, 0, 2, 8, 8, 128, 2, 2, 2, 4, 0, 1)
-VG_PICK(32, 1, 1, 8, 32, 64, 2, 4, 2, 4, 0, 1)
-VG_PICK(16, 1, 1, 16, 16, 64, 2, 4, 2, 4, 0, 1)
-VG_PICK(8, 1, 4, 8, 8, 64, 2, 4, 2, 4, 0, 1)
-VG_PICK(32, 2, 1, 2, 32, 64, 2, 2, 2, 4, 0, 1)
-VG_PICK(16, 2, 1, 4, 16, 64, 2, 2, 2, 4, 0, 1)
-VG_PICK(8, 2, 1, 8, 8, 64, 2, 2, 2, 4, 0, 1)
-VG_PICK(32, 3, 1, 4, 32, 64, 2, 2, 2, 4, 0, 1)
-VG_PICK(16, 3, 1, 8, 16, 64, 2, 2, 2, 4, 0, 1)
-VG_PICK(8, 3, 2, 8, 8, 64, 2, 2, 2, 4, 0, 1)
-VG_PICK(32, 4, 1, 8, 32, 128, 2, 4, 2, 4, 0, 1)
-VG_PICK(16, 4, 1, 16, 16, 128, 2, 4, 2, 4, 0, 1)
-VG_PICK(8, 4, 4, 8, 8, 128, 2, 4, 2, 4, 0, 1)
-VG_PICK(32, 5, 1, 4, 32, 64, 2, 2, 4, 8, 0, 2)
-VG_PICK(16, 5, 1, 8, 16, 64, 2, 2, 4, 8, 0, 2)
-VG_PICK(8, 5, 2, 8, 8, 64, 2, 2, 4, 8, 0, 2)
-VG_PICK(32, 6, 1, 4, 32, 32, 1, 4, 2, 4, 0, 1)
-VG_PICK(16, 6, 1, 8, 16, 32, 1, 4, 2, 4, 0, 1)
-VG_PICK(8, 6, 2, 8, 8, 32, 1, 4, 2, 4, 0, 1)
+//       W  V NB TH TW   TN WC WP CKF CKT KS
+VG_PICK(32, 0, 1, 4, 32, 128, 2, 2, 2, 4, 1)
+VG_PICK(16, 0, 1, 8, 16, 128, 2, 2, 2, 4, 1)
+VG_PICK(8, 0, 2, 8, 8, 128, 2, 2, 2, 4, 1)
+VG_PICK(32, 1, 1, 8, 32, 64, 2, 4, 2, 4, 1)
+VG_PICK(16, 1, 1, 16, 16, 64, 2, 4, 2, 4, 1)
+VG_PICK(8, 1, 4, 8, 8, 64, 2, 4, 2, 4, 1)
+VG_PICK(32, 2, 1, 2, 32, 64, 2, 2, 2, 4, 1)
+VG_PICK(16, 2, 1, 4, 16, 64, 2, 2, 2, 4, 1)
+VG_PICK(8, 2, 1, 8, 8, 64, 2, 2, 2, 4, 1)
+VG_PICK(32, 3, 1, 4, 32, 64, 2, 2, 2, 4, 1)
+VG_PICK(16, 3, 1, 8, 16, 64, 2, 2, 2, 4, 1)
+VG_PICK(8, 3, 2, 8, 8, 64, 2, 2, 2, 4, 1)
+VG_PICK(32, 4, 1, 8, 32, 128, 2, 4, 2, 4, 1)
+VG_PICK(16, 4, 1, 16, 16, 128, 2, 4, 2, 4, 1)
+VG_PICK(8, 4, 4, 8, 8, 128, 2, 4, 2, 4, 1)
+VG_PICK(32, 5, 1, 4, 32, 64, 2, 2, 4, 8, 2)
+VG_PICK(16, 5, 1, 8, 16, 64, 2, 2, 4, 8, 2)
+VG_PICK(8, 5, 2, 8, 8, 64, 2, 2, 4, 8, 2)
+VG_PICK(32, 6, 1, 4, 32, 32, 1, 4, 2, 4, 1)
+VG_PICK(16, 6, 1, 8, 16, 32, 1, 4, 2, 4, 1)
+VG_PICK(8, 6, 2, 8, 8, 32, 1, 4, 2, 4, 1)
 // thin outputs, 256 px x 32 cout, 8 waves along the pixels
-VG_PICK(32, 7, 1, 8, 32, 32, 1, 8, 2, 4, 0, 1)
-VG_PICK(16, 7, 1, 16, 16, 32, 1, 8, 2, 4, 0, 1)
-VG_PICK(8, 7, 4, 8, 8, 32, 1, 8, 2, 4, 0, 1)
+VG_PICK(32, 7, 1, 8, 32, 32, 1, 8, 2, 4, 1)
+VG_PICK(16, 7, 1, 16, 16, 32, 1, 8, 2, 4, 1)
+VG_PICK(8, 7, 4, 8, 8, 32, 1, 8, 2, 4, 1)
 #undef VG_PICK
 constexpr int NVAR = 8;
 

@@ -220,3 +220,24 @@ def test_losses_full_size(H):
 def test_rejects_cpu_tensors(H):
     with pytest.raises(RuntimeError):
         H.conv5x5_fwd(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 5, 5), None, 2)
+
+
+@pytest.mark.parametrize("variant", range(8))
+def test_every_tile_variant(H, variant):
+    """The dispatcher picks tiles by grid size; force each of the 8 tile variants of the
+    implicit-GEMM kernels (forward and transposed) on shapes that exercise partial tiles."""
+    from disentangle_mlp_amd import _lib
+    lib = _lib.load()
+    try:
+        for (B, Cin, Cout, Hs, Ws) in ((3, 10, 70, 16, 24), (5, 6, 33, 8, 8), (2, 4, 140, 40, 72)):
+            x, w = _rand(B, Cin, Hs, Ws, seed=40), 0.1 * _rand(Cout, Cin, 5, 5, seed=41)
+            lib.vg_debug_set_conv_tile(0, variant)
+            assert_close(H.conv5x5_fwd(x.cuda(), w.cuda(), None, 2), O.conv5x5(x, w, None, 2), 3e-6,
+                         f"fwd variant {variant}")
+            wt = 0.1 * _rand(Cin, Cout, 5, 5, seed=42)
+            lib.vg_debug_set_conv_tile(1, variant)
+            assert_close(H.convT5x5_fwd(x.cuda(), wt.cuda(), None, 2), O.convT5x5(x, wt, None, 2), 3e-6,
+                         f"tr variant {variant}")
+    finally:
+        lib.vg_debug_set_conv_tile(0, -1)
+        lib.vg_debug_set_conv_tile(1, -1)
