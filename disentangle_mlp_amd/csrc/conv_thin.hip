@@ -22,6 +22,8 @@ __global__ __launch_bounds__(NT) void convT_s1_thin_kernel(const float* __restri
                                                            const float* __restrict__ bias, float* __restrict__ y,
                                                            int Cin, int H, int W, int tiles_w, int tiles_hw) {
   __shared__ __attribute__((aligned(16))) float patch[CK * PH * PWS];
+  // filter taps of the chunk: [c][kh][co*5+kw] padded to 16 floats -> four broadcast b128 reads
+  __shared__ __attribute__((aligned(16))) float wl[CK * 5 * 16];
   const int tid = threadIdx.x;
   const int b = blockIdx.x / tiles_hw, sp = blockIdx.x % tiles_hw;
   const int oh0 = (sp / tiles_w) * TH, ow0 = (sp % tiles_w) * TW;
@@ -35,34 +37,44 @@ __global__ __launch_bounds__(NT) void convT_s1_thin_kernel(const float* __restri
 #pragma unroll
     for (int p = 0; p < 4; ++p) acc[co][p] = 0.f;
 
+  for (int e = tid; e < CK * PH * PWS; e += NT) patch[e] = 0.f;   // halo words stay 0 for the whole kernel
+  __syncthreads();
+
   for (int c0 = 0; c0 < Cin; c0 += CK) {
-    // stage patch rows oh0-2 .. oh0+TH+1, cols ow0-2 .. ow0+TW+1 of CK channels: a wavefront
-    // copies one 68-float row per step (64 lanes + a 4-lane tail), no index division
+    // stage patch rows oh0-2 .. oh0+TH+1, cols ow0-2 .. ow0+TW+1 of CK channels with direct
+    // global -> LDS loads (no VGPR round trip, all of a wave's rows in flight at once): a
+    // wavefront copies one 68-float row per step (64 lanes + a 4-lane tail).  Lanes / rows
+    // outside the image are masked off; those LDS words were zeroed once before the loop (the
+    // halo pattern of a tile is the same for every chunk) -- only a channel tail is re-zeroed.
     {
       const int lane = tid & 63, wid = tid >> 6;
       for (int rr = wid; rr < CK * PH; rr += NT / 64) {
         const int c = rr / PH, pr = rr - c * PH;
         const int ih = oh0 - 2 + pr;
-        const bool rok = (c0 + c) < Cin && ih >= 0 && ih < H;
-        const float* src = xb + (rok ? (size_t)(c0 + c) * HW + (size_t)ih * W : 0);
-        {
-          const int iw = ow0 - 2 + lane;
-          const bool ok = rok && iw >= 0 && iw < W;
-          const float v = src[ok ? iw : 0];
-          patch[rr * PWS + lane] = ok ? v : 0.f;
+        const bool cok = (c0 + c) < Cin;
+        const bool rok = cok && ih >= 0 && ih < H;
+        const float* src = xb + (size_t)min(c0 + c, Cin - 1) * HW + (size_t)min(max(ih, 0), H - 1) * W;
+        const int iw0 = ow0 - 2 + lane, iw1 = iw0 + 64;
+        if (rok && iw0 >= 0 && iw0 < W)
+          __builtin_amdgcn_global_load_lds(src + iw0, patch + rr * PWS, 4, 0, 0);
+        if (rok && lane < PWS - 64 && iw1 >= 0 && iw1 < W)
+          __builtin_amdgcn_global_load_lds(src + iw1, patch + rr * PWS + 64, 4, 0, 0);
+        if (!cok && ih >= 0 && ih < H) {      // channel tail (Cin % CK != 0): stale data -> 0
+          patch[rr * PWS + lane] = 0.f;
+          if (lane < PWS - 64) patch[rr * PWS + 64 + lane] = 0.f;
         }
-        if (lane < PWS - 64) {
-          const int iw = ow0 - 2 + 64 + lane;
-          const bool ok = rok && iw >= 0 && iw < W;
-          const float v = src[ok ? iw : 0];
-          patch[rr * PWS + 64 + lane] = ok ? v : 0.f;
-        }
+      }
+      for (int e = tid; e < CK * 5 * 16; e += NT) {
+        const int j = e & 15, kh = (e >> 4) % 5, c = e / 80;
+        const int co = j / 5, kw = j - co * 5;
+        const bool ok = j < COUT * 5 && (c0 + c) < Cin;
+        const float v = w[((size_t)min(c0 + c, Cin - 1) * COUT + min(co, COUT - 1)) * 25 + kh * 5 + kw];
+        wl[e] = ok ? v : 0.f;
       }
     }
     __syncthreads();
     const int cmax = min(CK, Cin - c0);
     for (int c = 0; c < cmax; ++c) {
-      const float* wc = w + (size_t)(c0 + c) * COUT * 25;   // wave-uniform: scalar loads
 #pragma unroll
       for (int kh = 0; kh < 5; ++kh) {
         // output row r needs input row r+2-kh  ->  patch row r + 4 - kh
@@ -70,13 +82,17 @@ __global__ __launch_bounds__(NT) void convT_s1_thin_kernel(const float* __restri
         const f32x4 lo = *reinterpret_cast<const f32x4*>(row);
         const f32x4 hi = *reinterpret_cast<const f32x4*>(row + 4);
         const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const f32x4* wq = reinterpret_cast<const f32x4*>(wl + (c * 5 + kh) * 16);   // uniform: broadcast
+        const f32x4 w0 = wq[0], w1 = wq[1], w2 = wq[2], w3 = wq[3];
+        const float wv[16] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3],
+                              w2[0], w2[1], w2[2], w2[3], w3[0], w3[1], w3[2], w3[3]};
 #pragma unroll
         for (int kw = 0; kw < 5; ++kw) {
 #pragma unroll
           for (int co = 0; co < COUT; ++co) {
-            const float wv = wc[co * 25 + kh * 5 + kw];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) acc[co][p] = fmaf(v[p + 4 - kw], wv, acc[co][p]);   // iw = ow+2-kw
+            for (int p = 0; p < 4; ++p)
+              acc[co][p] = fmaf(v[p + 4 - kw], wv[co * 5 + kw], acc[co][p]);   // iw = ow+2-kw
           }
         }
       }
