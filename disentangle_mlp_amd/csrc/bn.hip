@@ -103,59 +103,6 @@ __global__ __launch_bounds__(NT) void bn_partial_kernel(const float* __restrict_
   }
 }
 
-__global__ __launch_bounds__(NT) void bn_fwd_finalize_kernel(const double* __restrict__ part, int ns, int C,
-                                                             double count, float eps, float momentum,
-                                                             float* __restrict__ running_mean,
-                                                             float* __restrict__ running_var,
-                                                             float* __restrict__ save_mean,
-                                                             float* __restrict__ save_invstd,
-                                                             const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta,
-                                                             float4* __restrict__ cf) {
-  const int c = blockIdx.x * NT + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < ns; ++k) {
-    s1 += part[((size_t)c * ns + k) * 2];
-    s2 += part[((size_t)c * ns + k) * 2 + 1];
-  }
-  const double m = s1 / count;
-  double var = s2 / count - m * m;
-  if (var < 0.0) var = 0.0;
-  const float mu = (float)m, is = (float)(1.0 / sqrt(var + (double)eps));
-  save_mean[c] = mu;
-  save_invstd[c] = is;
-  const float sc = gamma[c] * is;
-  cf[c] = make_float4(sc, beta[c] - mu * sc, mu, is);
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
-  if (running_var) {
-    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
-  }
-}
-
-__global__ __launch_bounds__(NT) void bn_bwd_finalize_kernel(const double* __restrict__ part, int ns, int C,
-                                                             double count, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta,
-                                                             const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta,
-                                                             const float* __restrict__ mean,
-                                                             const float* __restrict__ invstd,
-                                                             float4* __restrict__ cf, float2* __restrict__ cb) {
-  const int c = blockIdx.x * NT + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < ns; ++k) {
-    s1 += part[((size_t)c * ns + k) * 2];
-    s2 += part[((size_t)c * ns + k) * 2 + 1];
-  }
-  if (dbeta) dbeta[c] = (float)s1;
-  if (dgamma) dgamma[c] = (float)s2;
-  const float mu = mean[c], is = invstd[c], sc = gamma[c] * is;
-  cf[c] = make_float4(sc, beta[c] - mu * sc, mu, is);
-  cb[c] = make_float2((float)(s1 / count), (float)(s2 / count));
-}
-
 __global__ __launch_bounds__(NT) void channel_sum_finalize_kernel(const double* __restrict__ part, int ns, int C,
                                                                   float* __restrict__ out) {
   const int c = blockIdx.x * NT + threadIdx.x;
@@ -165,45 +112,101 @@ __global__ __launch_bounds__(NT) void channel_sum_finalize_kernel(const double* 
   out[c] = (float)s1;
 }
 
-// Flat float4 stream over [B][C][HW]; per-channel coefficients come from the small
-// cf/cb tables written by the finalize kernels (L1/L2 resident).
-// FWD: y = act(x*sc + sh).   BWD: gx = sc * (g_pre - c1 - xhat*c2).
+// Normalise (FWD) or input-gradient (BWD) pass with the per-channel finalisation folded in: a
+// workgroup owns one slice of ONE channel, re-derives that channel's coefficients from the
+// (<= 64) fp64 partial sums in a fixed order -- no separate finalize launch, no coefficient
+// table, coefficients live in registers -- and streams its slice as float4.  The slice-0
+// workgroup of a channel also writes the saved / running statistics (FWD) or dgamma / dbeta (BWD).
+//   FWD: y  = act(x*sc + sh)            sc = gamma*invstd, sh = beta - mean*sc
+//   BWD: gx = sc * (g_pre - c1 - xhat*c2),  c1 = sum(g_pre)/N, c2 = sum(g_pre*xhat)/N
 template <bool BWD>
 __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                      const float4* __restrict__ cf,
-                                                      const float2* __restrict__ cb, float* __restrict__ out,
-                                                      int C, int HW, size_t n, int act) {
-  auto one = [&](float xv, float gv, const float4& f, const float2& bw) -> float {
-    const float pre = fmaf(xv, f.x, f.y);
+                                                      const double* __restrict__ part, int ns,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ mean_io,
+                                                      float* __restrict__ invstd_io,
+                                                      float* __restrict__ running_mean,
+                                                      float* __restrict__ running_var, float* __restrict__ dgamma,
+                                                      float* __restrict__ dbeta, float* __restrict__ out, int B,
+                                                      int C, int HW, long per, float eps, float momentum, int act) {
+  __shared__ float s_co[4];
+  const int c = blockIdx.x, k = blockIdx.y;
+  const double count = (double)B * HW;
+  if (threadIdx.x < 64) {   // wavefront 0: fixed-order reduction of the slice partials
+    double s1 = 0.0, s2 = 0.0;
+    for (int j = threadIdx.x; j < ns; j += 64) {
+      s1 += part[((size_t)c * ns + j) * 2];
+      s2 += part[((size_t)c * ns + j) * 2 + 1];
+    }
+    s1 = wave_allsum(s1);
+    s2 = wave_allsum(s2);
+    if (threadIdx.x == 0) {
+      if (!BWD) {
+        const double m = s1 / count;
+        double var = s2 / count - m * m;
+        if (var < 0.0) var = 0.0;
+        const float mu = (float)m, is = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * is;
+        s_co[0] = sc;
+        s_co[1] = beta[c] - mu * sc;
+        if (k == 0) {
+          mean_io[c] = mu;
+          invstd_io[c] = is;
+          if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+          if (running_var) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+          }
+        }
+      } else {
+        const float mu = mean_io[c], is = invstd_io[c], sc = gamma[c] * is;
+        s_co[0] = sc;
+        s_co[1] = beta[c] - mu * sc;
+        s_co[2] = (float)(s1 / count);
+        s_co[3] = (float)(s2 / count);
+        if (k == 0) {
+          if (dbeta) dbeta[c] = (float)s1;
+          if (dgamma) dgamma[c] = (float)s2;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const float sc = s_co[0], sh = s_co[1];
+  float c1 = 0.f, c2 = 0.f, mu = 0.f, is = 0.f;
+  if (BWD) {
+    c1 = s_co[2];
+    c2 = s_co[3];
+    mu = mean_io[c];
+    is = invstd_io[c];
+  }
+  auto one = [&](float xv, float gv) -> float {
+    const float pre = fmaf(xv, sc, sh);
     if (!BWD) return act_fwd(pre, act);
     const float g = act_grad(pre, gv, act);
-    return f.x * (g - bw.x - ((xv - f.z) * f.w) * bw.y);
+    return sc * (g - c1 - ((xv - mu) * is) * c2);
   };
-  const size_t stride = (size_t)gridDim.x * NT;
+  const long total = (long)B * HW;
+  const long v0 = (long)k * per, v1 = min(v0 + per, total);
   if ((HW & 3) == 0) {
-    const size_t n4 = n >> 2;
-    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += stride) {
-      const int c = (int)(((i << 2) / HW) % C);
-      const float4 f = cf[c];
-      float2 bw = make_float2(0.f, 0.f);
-      if (BWD) bw = cb[c];
-      const float4 xv = reinterpret_cast<const float4*>(x)[i];
+    for (long v = v0 + 4L * threadIdx.x; v < v1; v += 4L * NT) {
+      const long b = v / HW, hw = v - b * HW;
+      const size_t off = ((size_t)b * C + c) * HW + hw;
+      const float4 xv = *reinterpret_cast<const float4*>(x + off);
       float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (BWD) gv = reinterpret_cast<const float4*>(gy)[i];
+      if (BWD) gv = *reinterpret_cast<const float4*>(gy + off);
       float4 o;
-      o.x = one(xv.x, gv.x, f, bw);
-      o.y = one(xv.y, gv.y, f, bw);
-      o.z = one(xv.z, gv.z, f, bw);
-      o.w = one(xv.w, gv.w, f, bw);
-      reinterpret_cast<float4*>(out)[i] = o;
+      o.x = one(xv.x, gv.x);
+      o.y = one(xv.y, gv.y);
+      o.z = one(xv.z, gv.z);
+      o.w = one(xv.w, gv.w);
+      *reinterpret_cast<float4*>(out + off) = o;
     }
   } else {
-    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) {
-      const int c = (int)((i / HW) % C);
-      const float4 f = cf[c];
-      float2 bw = make_float2(0.f, 0.f);
-      if (BWD) bw = cb[c];
-      out[i] = one(x[i], BWD ? gy[i] : 0.f, f, bw);
+    for (long v = v0 + threadIdx.x; v < v1; v += NT) {
+      const long b = v / HW, hw = v - b * HW;
+      const size_t off = ((size_t)b * C + c) * HW + hw;
+      out[off] = one(x[off], BWD ? gy[off] : 0.f);
     }
   }
 }
@@ -321,11 +324,7 @@ __global__ __launch_bounds__(NT) void bn1d_bwd_kernel(const float* __restrict__ 
 }
 
 size_t part_bytes(int C) { return (size_t)C * NS_MAX * 2 * sizeof(double); }
-size_t ws_bytes(int C) { return part_bytes(C) + (size_t)C * (sizeof(float4) + sizeof(float2)) + 64; }
-int apply_grid(size_t n) {
-  const size_t blocks = (n / 4 + NT - 1) / NT;
-  return (int)(blocks > 4096 ? 4096 : (blocks < 1 ? 1 : blocks));
-}
+size_t ws_bytes(int C) { return part_bytes(C) + 64; }
 
 }  // namespace
 
@@ -351,14 +350,9 @@ extern "C" int vg_bn_act_fwd(const float* x, const float* gamma, const float* be
   hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(C, s.ns), dim3(NT), 0, st, x, (const float*)nullptr, gamma, beta,
                      (const float*)nullptr, (const float*)nullptr, part, B, C, HW, s.per, s.ns, act);
   VG_CHECK_LAUNCH();
-  float4* cf = (float4*)((char*)workspace + part_bytes(C));
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(C, NT)), dim3(NT), 0, st, (const double*)part, s.ns, C,
-                     (double)B * HW, eps, momentum, running_mean, running_var, save_mean, save_invstd, gamma, beta,
-                     cf);
-  VG_CHECK_LAUNCH();
-  const size_t n = (size_t)B * C * HW;
-  hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(apply_grid(n)), dim3(NT), 0, st, x, (const float*)nullptr,
-                     (const float4*)cf, (const float2*)nullptr, y, C, HW, n, act);
+  hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(C, s.ns), dim3(NT), 0, st, x, (const float*)nullptr,
+                     (const double*)part, s.ns, gamma, beta, save_mean, save_invstd, running_mean, running_var,
+                     (float*)nullptr, (float*)nullptr, y, B, C, HW, s.per, eps, momentum, act);
   VG_CHECK_LAUNCH();
   return 0;
 }
@@ -379,18 +373,13 @@ extern "C" int vg_bn_act_bwd(const float* gy, const float* x, const float* gamma
   }
   if (!workspace || workspace_bytes < ws_bytes(C)) return VG_ERR_WORKSPACE;
   double* part = (double*)workspace;
-  float4* cf = (float4*)((char*)workspace + part_bytes(C));
-  float2* cb = (float2*)(cf + C);
   const Slicing s = make_slicing(B, C, HW);
   hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(C, s.ns), dim3(NT), 0, st, x, gy, gamma, beta, save_mean,
                      save_invstd, part, B, C, HW, s.per, s.ns, act);
   VG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, NT)), dim3(NT), 0, st, (const double*)part, s.ns, C,
-                     (double)B * HW, dgamma, dbeta, gamma, beta, save_mean, save_invstd, cf, cb);
-  VG_CHECK_LAUNCH();
-  const size_t n = (size_t)B * C * HW;
-  hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(apply_grid(n)), dim3(NT), 0, st, x, gy, (const float4*)cf,
-                     (const float2*)cb, gx, C, HW, n, act);
+  hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(C, s.ns), dim3(NT), 0, st, x, gy, (const double*)part, s.ns, gamma,
+                     beta, const_cast<float*>(save_mean), const_cast<float*>(save_invstd), (float*)nullptr,
+                     (float*)nullptr, dgamma, dbeta, gx, B, C, HW, s.per, 0.f, 0.f, act);
   VG_CHECK_LAUNCH();
   return 0;
 }
