@@ -230,3 +230,43 @@ def test_flat_gradient_buffers_match_plain_path(T):
     for (k, a), (_, c) in zip(res[0][1].netD.state_dict().items(), res[1][1].netD.state_dict().items()):
         assert float((a.double() - c.double()).abs().max()) <= 2.1e-3, k     # <= one Adam sign flip
         assert float((a.double() - c.double()).abs().mean()) <= 1e-6, k
+
+
+def test_encoder_celeba_and_random_eps_paths(T):
+    """Encoder_celeba (model.py:282-328) returns (z, per-sample kld); VAE.forward draws eps itself
+    when none is injected (model.py:534)."""
+    import oracle
+    from disentangle_mlp_amd import model as M
+    torch.manual_seed(5)
+    ref = oracle.Encoder_celeba(oracle.OracleOpt())
+    enc = M.Encoder_celeba(T.ModelOpt())
+    enc.load_state_dict(ref.state_dict())
+    enc = enc.cuda()
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(6, 3, 64, 64, generator=g) * 2 - 1
+    eps = torch.randn(6, 128, generator=g)
+    with torch.no_grad():
+        z_ref, kld_ref = ref(x, eps)
+    z, kld = enc(x.cuda(), eps.cuda())
+    assert z.shape == (6, 128) and kld.shape == (6,)
+    assert float((z.cpu() - z_ref).norm() / z_ref.norm()) < 2e-5
+    assert float((kld.cpu() - kld_ref).norm() / kld_ref.norm()) < 2e-5
+    z.sum().backward()                                   # gradient flows to the trunk
+    assert enc.features[0].weight.grad is not None and float(enc.features[0].weight.grad.abs().sum()) > 0
+    vae = M.VAE(T.ModelOpt()).cuda()
+    r1, mu1, _ = vae(x.cuda())
+    r2, mu2, _ = vae(x.cuda())
+    assert r1.shape == (6, 3, 64, 64) and float((r1 - r2).abs().max()) > 0       # fresh eps each call
+    assert float(r1.abs().max()) <= 1.0                                           # tanh range
+
+
+def test_load_accepts_prefixless_discriminator_keys(T):
+    """test.py-era checkpoints store netD without the DataParallel 'module.' prefix
+    (utils/generate_samples_recons.py:23,31); load() takes both layouts."""
+    tr = T.BetaVAEGANTrainer()
+    ck = tr.checkpoint(3)
+    ck["discriminator_model"] = {k[len("module."):]: v for k, v in ck["discriminator_model"].items()}
+    tr2 = T.BetaVAEGANTrainer(seed=2)
+    assert tr2.load(ck) == 3
+    for (k, a), (_, b) in zip(tr.netD.state_dict().items(), tr2.netD.state_dict().items()):
+        assert torch.equal(a, b), k
