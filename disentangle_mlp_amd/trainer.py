@@ -276,8 +276,10 @@ class BetaVAEGANTrainer:
             "discriminator_optimizer": self.optimizerD.state_dict(),
         }
 
-    def save(self, path, epoch):
-        torch.save(self.checkpoint(epoch), path)
+    def save(self, path, epoch, legacy_format=False):
+        """torch.save of the reference's dict (new_betavaegan.py:222-228).  ``legacy_format=True``
+        writes the pre-1.6 (non-zip) pickle that the reference's pinned torch 1.3.1 can read."""
+        torch.save(self.checkpoint(epoch), path, _use_new_zipfile_serialization=not legacy_format)
 
     def load(self, path_or_dict):
         ck = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location=self.device)
