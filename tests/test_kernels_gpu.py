@@ -241,3 +241,75 @@ def test_every_tile_variant(H, variant):
     finally:
         lib.vg_debug_set_conv_tile(0, -1)
         lib.vg_debug_set_conv_tile(1, -1)
+
+
+# ------------------------------------------------------------ full-size properties (B = 128)
+def _dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+@pytest.mark.parametrize("Cin,Cout,Hs,stride", CONV_LAYERS)
+def test_full_size_conv_adjoints(H, Cin, Cout, Hs, stride):
+    """BASELINE batch (128): <conv(x,w), g> == <x, dgrad(g,w)> == <w, wgrad(x,g)> (the three
+    kernels are transposes of one bilinear map), and the forward is linear in x."""
+    B = 128
+    gen = torch.Generator(device="cuda").manual_seed(50)
+    x = torch.randn(B, Cin, Hs, Hs, device="cuda", generator=gen)
+    w = 0.05 * torch.randn(Cout, Cin, 5, 5, device="cuda", generator=gen)
+    y = H.conv5x5_fwd(x, w, None, stride)
+    g = torch.randn(y.shape, device="cuda", generator=gen)
+    s_fwd = _dot(y, g)
+    s_dgrad = _dot(x, H.convT5x5_fwd(g, w, None, stride))
+    s_wgrad = _dot(w, H.conv5x5_wgrad(x, g, stride))
+    scale = float(y.double().norm() * g.double().norm())
+    assert abs(s_fwd - s_dgrad) <= 2e-6 * scale, (s_fwd, s_dgrad, scale)
+    assert abs(s_fwd - s_wgrad) <= 2e-6 * scale, (s_fwd, s_wgrad, scale)
+    x2 = torch.randn(x.shape, device="cuda", generator=gen)
+    lin = H.conv5x5_fwd(0.5 * x + x2, w, None, stride) - (0.5 * y + H.conv5x5_fwd(x2, w, None, stride))
+    assert float(lin.double().norm()) <= 3e-6 * float(y.double().norm()) * 3
+
+
+@pytest.mark.parametrize("Cin,Cout,Hs,stride", CONVT_LAYERS)
+def test_full_size_convT_adjoints(H, Cin, Cout, Hs, stride):
+    B = 128
+    gen = torch.Generator(device="cuda").manual_seed(51)
+    x = torch.randn(B, Cin, Hs, Hs, device="cuda", generator=gen)
+    w = 0.05 * torch.randn(Cin, Cout, 5, 5, device="cuda", generator=gen)
+    b = torch.randn(Cout, device="cuda", generator=gen)
+    y0 = H.convT5x5_fwd(x, w, None, stride)
+    g = torch.randn(y0.shape, device="cuda", generator=gen)
+    s_fwd = _dot(y0, g)
+    s_dgrad = _dot(x, H.conv5x5_fwd(g, w, None, stride))
+    s_wgrad = _dot(w, H.conv5x5_wgrad(g, x, stride))
+    scale = float(y0.double().norm() * g.double().norm())
+    assert abs(s_fwd - s_dgrad) <= 2e-6 * scale
+    assert abs(s_fwd - s_wgrad) <= 2e-6 * scale
+    yb = H.convT5x5_fwd(x, w, b, stride)                 # bias is added once per output channel
+    assert float(((yb - y0) - b.view(1, -1, 1, 1)).abs().max()) <= 1e-5 * float(y0.abs().max())
+
+
+@pytest.mark.parametrize("shape", [(128, 32, 64, 64), (128, 256, 8, 8), (128, 16384)])
+def test_full_size_batchnorm_properties(H, shape):
+    """Train-mode BN at BASELINE sizes: normalised output has per-channel mean beta and variance
+    gamma^2; its input gradient is orthogonal to 1 and to x_hat (the two projections BN removes)."""
+    gen = torch.Generator(device="cuda").manual_seed(52)
+    x = 3 * torch.randn(shape, device="cuda", generator=gen) + 1.5
+    C = shape[1]
+    gamma = 1 + 0.1 * torch.randn(C, device="cuda", generator=gen)
+    beta = 0.1 * torch.randn(C, device="cuda", generator=gen)
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    y, mean, invstd = H.bn_act_fwd(x, gamma, beta, rm, rv, 1e-5, 0.1, 0)
+    dims = [0] + list(range(2, len(shape)))
+    yd = y.double()
+    assert float((yd.mean(dims) - beta.double()).abs().max()) <= 2e-5
+    assert float((yd.var(dims, unbiased=False).sqrt() - gamma.double().abs()).abs().max()) <= 2e-4
+    assert float((rm.double() - 0.1 * x.double().mean(dims)).abs().max()) <= 1e-5
+    gy = torch.randn(shape, device="cuda", generator=gen)
+    gx, dg, db = H.bn_act_bwd(gy, x, gamma, beta, mean, invstd, 0)
+    view = [1, C] + [1] * (len(shape) - 2)
+    xhat = (x.double() - mean.double().view(view)) * invstd.double().view(view)
+    n = x.numel() / C
+    gxd = gx.double()
+    assert float(gxd.sum(dims).abs().max()) <= 1e-4 * float(gxd.abs().sum(dims).max())
+    assert float((gxd * xhat).sum(dims).abs().max()) <= 1e-4 * float(gxd.abs().sum(dims).max()) * 3
+    assert float((db.double() - gy.double().sum(dims)).abs().max()) <= 1e-4 * n ** 0.5
