@@ -68,11 +68,13 @@ def cpu_baseline(batch, beta):
     wb = osteps.synthetic_batch(8)
     osteps.betavaegan_step(eg, d, oeg, od, wb["data"], wb["noise"], wb["eps2"], wb["eps3"], beta=beta)
     b = osteps.synthetic_batch(batch)
+    n_it = 2
     t0 = time.perf_counter()
-    osteps.betavaegan_step(eg, d, oeg, od, b["data"], b["noise"], b["eps2"], b["eps3"], beta=beta)
+    for _ in range(n_it):
+        osteps.betavaegan_step(eg, d, oeg, od, b["data"], b["noise"], b["eps2"], b["eps3"], beta=beta)
     dt = time.perf_counter() - t0
-    return {"value": round(batch / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"1 full beta-VAE-GAN iteration at batch {batch} (after a batch-8 warm-up), "
+    return {"value": round(n_it * batch / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{n_it} full beta-VAE-GAN iterations at batch {batch} (after a batch-8 warm-up), "
                       f"torch CPU fp32, {threads} threads, {dt:.2f} s"}
 
 
