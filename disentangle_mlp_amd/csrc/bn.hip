@@ -129,6 +129,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
                                                       float* __restrict__ running_var, float* __restrict__ dgamma,
                                                       float* __restrict__ dbeta, float* __restrict__ out, int B,
                                                       int C, int HW, long per, float eps, float momentum, int act) {
+  // `per`: elements of this channel per workgroup of THIS pass (independent of the partial pass)
   __shared__ float s_co[4];
   const int c = blockIdx.x, k = blockIdx.y;
   const double count = (double)B * HW;
@@ -323,6 +324,21 @@ __global__ __launch_bounds__(NT) void bn1d_bwd_kernel(const float* __restrict__ 
   }
 }
 
+// slices of the apply pass: >= 4096 elements per workgroup so that the per-workgroup prologue (partials
+// reduction + barrier) is amortised, but enough workgroups to fill the chip
+Slicing make_apply_slicing(int B, int C, int HW) {
+  const long total = (long)B * HW;
+  long ns = 4096 / C;
+  if (ns < 1) ns = 1;
+  long per = (total + ns - 1) / ns;
+  if (per < 4096) per = 4096;
+  per = (per + 3) / 4 * 4;
+  Slicing s;
+  s.per = per;
+  s.ns = (int)((total + per - 1) / per);
+  return s;
+}
+
 size_t part_bytes(int C) { return (size_t)C * NS_MAX * 2 * sizeof(double); }
 size_t ws_bytes(int C) { return part_bytes(C) + 64; }
 
@@ -350,9 +366,10 @@ extern "C" int vg_bn_act_fwd(const float* x, const float* gamma, const float* be
   hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(C, s.ns), dim3(NT), 0, st, x, (const float*)nullptr, gamma, beta,
                      (const float*)nullptr, (const float*)nullptr, part, B, C, HW, s.per, s.ns, act);
   VG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(C, s.ns), dim3(NT), 0, st, x, (const float*)nullptr,
+  const Slicing a = make_apply_slicing(B, C, HW);
+  hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(C, a.ns), dim3(NT), 0, st, x, (const float*)nullptr,
                      (const double*)part, s.ns, gamma, beta, save_mean, save_invstd, running_mean, running_var,
-                     (float*)nullptr, (float*)nullptr, y, B, C, HW, s.per, eps, momentum, act);
+                     (float*)nullptr, (float*)nullptr, y, B, C, HW, a.per, eps, momentum, act);
   VG_CHECK_LAUNCH();
   return 0;
 }
@@ -377,9 +394,10 @@ extern "C" int vg_bn_act_bwd(const float* gy, const float* x, const float* gamma
   hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(C, s.ns), dim3(NT), 0, st, x, gy, gamma, beta, save_mean,
                      save_invstd, part, B, C, HW, s.per, s.ns, act);
   VG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(C, s.ns), dim3(NT), 0, st, x, gy, (const double*)part, s.ns, gamma,
+  const Slicing a = make_apply_slicing(B, C, HW);
+  hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(C, a.ns), dim3(NT), 0, st, x, gy, (const double*)part, s.ns, gamma,
                      beta, const_cast<float*>(save_mean), const_cast<float*>(save_invstd), (float*)nullptr,
-                     (float*)nullptr, dgamma, dbeta, gx, B, C, HW, s.per, 0.f, 0.f, act);
+                     (float*)nullptr, dgamma, dbeta, gx, B, C, HW, a.per, 0.f, 0.f, act);
   VG_CHECK_LAUNCH();
   return 0;
 }
