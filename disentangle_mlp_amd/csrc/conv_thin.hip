@@ -16,14 +16,16 @@ namespace {
 
 constexpr int TH = 16, TW = 64, CK = 8, PH = TH + 4, PWS = TW + 4;  // PWS % 4 == 0: aligned b128 reads
 constexpr int NT = 256;
+constexpr int WSLOT = 20;   // taps of one (channel, kh): up to 4 output channels x 5 kw
 
 template <int COUT>
 __global__ __launch_bounds__(NT) void convT_s1_thin_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ y,
                                                            int Cin, int H, int W, int tiles_w, int tiles_hw) {
   __shared__ __attribute__((aligned(16))) float patch[CK * PH * PWS];
-  // filter taps of the chunk: [c][kh][co*5+kw] padded to 16 floats -> four broadcast b128 reads
-  __shared__ __attribute__((aligned(16))) float wl[CK * 5 * 16];
+  // filter taps of the chunk: [c][kh][co*5+kw], 20 floats per (c, kh) (4 cout x 5 kw) -> five broadcast
+  // b128 reads
+  __shared__ __attribute__((aligned(16))) float wl[CK * 5 * WSLOT];
   const int tid = threadIdx.x;
   const int b = blockIdx.x / tiles_hw, sp = blockIdx.x % tiles_hw;
   const int oh0 = (sp / tiles_w) * TH, ow0 = (sp % tiles_w) * TW;
@@ -64,8 +66,8 @@ __global__ __launch_bounds__(NT) void convT_s1_thin_kernel(const float* __restri
           if (lane < PWS - 64) patch[rr * PWS + 64 + lane] = 0.f;
         }
       }
-      for (int e = tid; e < CK * 5 * 16; e += NT) {
-        const int j = e & 15, kh = (e >> 4) % 5, c = e / 80;
+      for (int e = tid; e < CK * 5 * WSLOT; e += NT) {
+        const int j = e % WSLOT, kh = (e / WSLOT) % 5, c = e / (5 * WSLOT);
         const int co = j / 5, kw = j - co * 5;
         const bool ok = j < COUT * 5 && (c0 + c) < Cin;
         const float v = w[((size_t)min(c0 + c, Cin - 1) * COUT + min(co, COUT - 1)) * 25 + kh * 5 + kw];
@@ -82,10 +84,16 @@ __global__ __launch_bounds__(NT) void convT_s1_thin_kernel(const float* __restri
         const f32x4 lo = *reinterpret_cast<const f32x4*>(row);
         const f32x4 hi = *reinterpret_cast<const f32x4*>(row + 4);
         const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        const f32x4* wq = reinterpret_cast<const f32x4*>(wl + (c * 5 + kh) * 16);   // uniform: broadcast
-        const f32x4 w0 = wq[0], w1 = wq[1], w2 = wq[2], w3 = wq[3];
-        const float wv[16] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3],
-                              w2[0], w2[1], w2[2], w2[3], w3[0], w3[1], w3[2], w3[3]};
+        const f32x4* wq = reinterpret_cast<const f32x4*>(wl + (c * 5 + kh) * WSLOT);   // uniform: broadcast
+        float wv[WSLOT];
+#pragma unroll
+        for (int j4 = 0; j4 < (COUT * 5 + 3) / 4; ++j4) {
+          const f32x4 t = wq[j4];
+          wv[4 * j4] = t[0];
+          wv[4 * j4 + 1] = t[1];
+          wv[4 * j4 + 2] = t[2];
+          wv[4 * j4 + 3] = t[3];
+        }
 #pragma unroll
         for (int kw = 0; kw < 5; ++kw) {
 #pragma unroll

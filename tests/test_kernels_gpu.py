@@ -313,3 +313,31 @@ def test_full_size_batchnorm_properties(H, shape):
     assert float(gxd.sum(dims).abs().max()) <= 1e-4 * float(gxd.abs().sum(dims).max())
     assert float((gxd * xhat).sum(dims).abs().max()) <= 1e-4 * float(gxd.abs().sum(dims).max()) * 3
     assert float((db.double() - gy.double().sum(dims)).abs().max()) <= 1e-4 * n ** 0.5
+
+
+def test_conv_random_shapes(H):
+    """Seeded sweep over 30 random (B, Cin, Cout, H, W, stride) shapes: every tile-tail / channel-
+    tail combination the dispatcher can hit, forward + both gradients + the transposed direction."""
+    import random
+    rng = random.Random(1234)
+    for case in range(30):
+        stride = rng.choice([1, 2])
+        B = rng.choice([1, 2, 3, 5, 9])
+        Cin = rng.choice([1, 2, 3, 5, 8, 17, 33])
+        Cout = rng.choice([1, 3, 4, 7, 32, 33, 65, 129])
+        Hs = rng.choice([2, 4, 6, 10, 16, 22]) * stride // stride
+        Ws = rng.choice([2, 4, 8, 14, 18, 34, 66])
+        if stride == 2:
+            Hs, Ws = Hs + Hs % 2, Ws + Ws % 2
+        x = _rand(B, Cin, Hs, Ws, seed=100 + case)
+        w, b = 0.2 * _rand(Cout, Cin, 5, 5, seed=200 + case), _rand(Cout, seed=300 + case)
+        tag = f"case {case}: B{B} Cin{Cin} Cout{Cout} {Hs}x{Ws} s{stride}"
+        y_ref = O.conv5x5(x, w, b, stride)
+        assert_close(H.conv5x5_fwd(x.cuda(), w.cuda(), b.cuda(), stride), y_ref, 3e-6, tag + " fwd")
+        gy = _rand(*y_ref.shape, seed=400 + case)
+        gx_ref, gw_ref = O.conv5x5_grads(x, w, gy, stride)
+        assert_close(H.convT5x5_fwd(gy.cuda(), w.cuda(), None, stride), gx_ref, 3e-6, tag + " dgrad")
+        assert_close(H.conv5x5_wgrad(x.cuda(), gy.cuda(), stride), gw_ref, 3e-6, tag + " wgrad")
+        wt = 0.2 * _rand(Cin, Cout, 5, 5, seed=500 + case)
+        assert_close(H.convT5x5_fwd(x.cuda(), wt.cuda(), b.cuda(), stride), O.convT5x5(x, wt, b, stride), 3e-6,
+                     tag + " convT")
