@@ -147,8 +147,12 @@ class FlatGrads:
                           for p in self.params])
 
 
-def _make_adam(params, lr, fused):
-    return optim.Adam(params, lr=lr, fused=fused) if fused else optim.Adam(params, lr=lr)
+def _make_adam(params, lr, fused, capturable=False):
+    """torch.optim.Adam with the reference's defaults (new_betavaegan.py:49-50).  ``capturable`` keeps the
+    step counters on the device so that a whole iteration can be captured in a HIP graph."""
+    if fused:
+        return optim.Adam(params, lr=lr, fused=True, capturable=capturable)
+    return optim.Adam(params, lr=lr, capturable=capturable)
 
 
 def _dist_world():
@@ -159,7 +163,7 @@ class BetaVAEGANTrainer:
     """One replica of the beta-VAE-GAN (new_betavaegan.py:36-53 construction recipe)."""
 
     def __init__(self, device="cuda", seed=999, beta=25.0, lr=1e-3, opt: Optional[ModelOpt] = None,
-                 data_parallel: Optional[bool] = None, fused_adam: bool = True):
+                 data_parallel: Optional[bool] = None, fused_adam: bool = True, capturable: bool = False):
         self.opt = opt or ModelOpt()
         self.device = torch.device(device)
         self.beta = float(beta)
@@ -171,8 +175,8 @@ class BetaVAEGANTrainer:
         self.netEG = net_eg.to(self.device)
         self.netD = net_d.to(self.device)
         fused = fused_adam and self.device.type == "cuda"
-        self.optimizerEG = _make_adam(self.netEG.parameters(), lr, fused)   # :49 (hard-coded 1e-3 there)
-        self.optimizerD = _make_adam(self.netD.parameters(), lr, fused)     # :50
+        self.optimizerEG = _make_adam(self.netEG.parameters(), lr, fused, capturable)   # :49 (hard-coded 1e-3 there)
+        self.optimizerD = _make_adam(self.netD.parameters(), lr, fused, capturable)     # :50
         self.world = _dist_world()
         self.dp = (self.world > 1) if data_parallel is None else data_parallel
         self.flat_eg = FlatGrads(self.netEG.parameters()) if self.dp else None
@@ -297,7 +301,7 @@ class VAETrainer:
     """new_vae.py:33-37 construction, :39-48 loss, :53-59 step."""
 
     def __init__(self, device="cuda", seed=999, beta=1.0, lr=3e-3, opt: Optional[ModelOpt] = None,
-                 fused_adam: bool = True):
+                 fused_adam: bool = True, capturable: bool = False):
         self.opt = opt or ModelOpt()
         self.device = torch.device(device)
         self.beta = float(beta)
@@ -305,7 +309,7 @@ class VAETrainer:
         m = VAE(self.opt)
         m.apply(weights_init)
         self.model = m.to(self.device)
-        self.optimizer = _make_adam(self.model.parameters(), lr, fused_adam and self.device.type == "cuda")
+        self.optimizer = _make_adam(self.model.parameters(), lr, fused_adam and self.device.type == "cuda", capturable)
         self.world = _dist_world()
         self.flat = FlatGrads(self.model.parameters()) if self.world > 1 else None
         self.model.train()
