@@ -9,7 +9,7 @@
 //                      model.py:558-564 (deconv1..4 at :495-507) and the data
 //                      gradient of the convolutions.
 //
-// Work decomposition (one 256-thread workgroup = 4 wavefronts of 64 lanes):
+// Work decomposition (one workgroup = 4 or 8 wavefronts of 64 lanes; tile variants below):
 //   * output tile = TN output channels ("rows" of D) x TM = NB*TH*TW pixels
 //     ("columns"): D[cout][pixel], so the 32 lanes of an MFMA column group store
 //     32 consecutive pixels of an NCHW row.
@@ -17,6 +17,9 @@
 //     workgroup stages into LDS (double buffered, next chunk prefetched into
 //     registers under the MFMAs): the NCHW input patch [NB][CK][PH][PW] with
 //     coalesced row loads and zero-filled halo, and the filter slab [TN][CK*NTAP].
+//     Staging loads are never predicated (addresses clamped into the tensor, halo
+//     zeroed at the LDS store): predicated loads made hipcc merge the dummy loads
+//     and drain vmcnt in the middle of the prefetch.
 //   * im2col never exists in memory: lane (j,h) reads patch[c0+2cp+h][...] at a
 //     per-lane base + compile-time immediate; one staged input pixel feeds up to
 //     25/S^2 MFMA operands.
