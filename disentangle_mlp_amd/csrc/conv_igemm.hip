@@ -33,10 +33,16 @@ namespace {
 
 enum { MODE_FWD = 0, MODE_TR = 1 };
 
-template <int MODE_, int S_, int NB_, int TH_, int TW_, int TN_, int WC_, int WP_, int CK_, int MINW_ = 2, int KS_ = 1>
+
+template <int MODE_, int S_, int NB_, int TH_, int TW_, int TN_, int WC_, int WP_, int CK_, int MINW_ = 2, int KS_ = 1,
+          bool PK_ = false>
 struct Cfg {
   static constexpr int MODE = MODE_, S = S_, NB = NB_, TH = TH_, TW = TW_, TN = TN_, WC = WC_, WP = WP_,
                        CK = CK_, MINW = MINW_, KS = KS_;  // KS: in-workgroup split of the K chunk
+  static constexpr bool PK = PK_;  // filter comes pre-packed [class][ci][tap][cout] (vg_conv5x5_pack)
+  // packed slab copied global -> LDS by DMA (no VGPR round trip): measured faster on the 8-wave
+  // tiles without K split, slower on the 4-wave ones (scripts/tune_conv.py)
+  static constexpr bool DMA = PK_ && WC_ * WP_ == 8 && KS_ == 1;
   static constexpr int NT = 64 * WC * WP * KS;
   static constexpr int TM = NB * TH * TW;
   static constexpr int FC = TN / 32 / WC;  // 32-row cout fragments per wave
@@ -49,7 +55,8 @@ struct Cfg {
   static constexpr int NQP = cdiv(NP, NT);
   static constexpr int RLMAX = CK * NTMAX * NTMAX;
   static constexpr int WSMAX = RLMAX | 1;
-  static constexpr int STAGE = NP + TN * WSMAX + 1;  // +1: dummy slot for masked-off stores
+  static constexpr int WOFF = (NP + 3) & ~3;         // filter slab starts 16-byte aligned
+  static constexpr int STAGE = (WOFF + TN * WSMAX + 1 + 3) & ~3;  // +1: dummy slot for masked-off stores
   static constexpr int NCLS = (MODE == MODE_FWD) ? 1 : S * S;
   static_assert(TN % (32 * WC) == 0 && TM % (32 * WP) == 0 && CK % 2 == 0, "tile shape");
   static_assert(RLMAX <= NT, "one filter row per pass at least");
@@ -59,19 +66,36 @@ struct Cfg {
 
 struct Args {
   const float* x;
-  const float* w;
+  const float* w;    // PK: the packed filter
   const float* bias;
   float* y;
   int B, Cin, XH, XW, Cout, YH, YW;
+  int CinP, CoutP;   // PK: padded extents of the packed filter
   int ntiles_n, tiles_w, tiles_hw, blocks_per_cls;
 };
+
+// Padded extents of the packed filter: whole K chunks (<= 8 channels) and whole cout tiles.
+__host__ __device__ constexpr int packed_cin(int Cin) { return (Cin + 7) & ~7; }
+__host__ __device__ constexpr int packed_cout(int Cout) { return (Cout + 127) & ~127; }
+
+// Taps of the parity classes that precede class (R, SS) in the packed filter.
+__host__ __device__ constexpr int taps_before(int S, int R, int SS) {
+  int n = 0;
+  for (int r = 0; r < S; ++r)
+    for (int s = 0; s < S; ++s) {
+      if (r == R && s == SS) return n;
+      n += ((5 - r + S - 1) / S) * ((5 - s + S - 1) / S);
+    }
+  return n;
+}
 
 // R, SS: output parity class of the transposed convolution (0,0 for MODE_FWD).
 template <class C, int R, int SS>
 __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) {
   constexpr int MODE = C::MODE, S = C::S, NB = C::NB, TH = C::TH, TW = C::TW, TN = C::TN, CK = C::CK;
   constexpr int NT = C::NT, FC = C::FC, FP = C::FP, PH = C::PH, PW = C::PW, PWP = C::PWP;
-  constexpr int NP = C::NP, NQP = C::NQP, NTMAX = C::NTMAX;
+  constexpr int NP = C::NP, NQP = C::NQP, NTMAX = C::NTMAX, WOFF = C::WOFF;
+  constexpr bool PK = C::PK;
   constexpr int NTH = (MODE == MODE_FWD) ? 5 : (5 - R + S - 1) / S;   // taps along h in this class
   constexpr int NTW = (MODE == MODE_FWD) ? 5 : (5 - SS + S - 1) / S;
   constexpr int NTAP = NTH * NTW;
@@ -147,7 +171,16 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
   const int w_ch_stride = (MODE == MODE_FWD) ? 25 : Cout * 25;
   const int w_tap = w_kh * 5 + w_kw;
 
-  float preg[NQP], wreg[NQW];
+  // ---- packed filter (PK): the chunk's slab is RL rows x TN floats of the [ci*NTAP+tap][CoutP]
+  // image, copied verbatim (16-byte loads / ds_write_b128, zero padding comes from the pack)
+  constexpr int TN4 = TN / 4, RPQ = NT / TN4;      // 16-byte columns per row; rows per pass
+  constexpr int NQ4 = PK ? cdiv(RL, RPQ) : 1;
+  static_assert(NT % TN4 == 0, "packed staging: whole rows per pass");
+  const int pk_c4 = tid % TN4, pk_k0 = tid / TN4;
+  const float* wpk = A.w + ((size_t)taps_before(S, R, SS) * A.CinP) * A.CoutP + n0 + 4 * pk_c4;
+
+  float preg[NQP], wreg[PK ? 1 : NQW];
+  f32x4 wreg4[NQ4];
   auto load_chunk = [&](int c0) {
 #pragma unroll
     for (int q = 0; q < NQP; ++q) {
@@ -155,11 +188,29 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
       const int c = (e / (PWP * PH)) % CK;
       preg[q] = xb[pofs[q] + min(c0 + c, Cin - 1) * HW];
     }
-    const int wbase = min(c0 + w_c, Cin - 1) * w_ch_stride + w_tap;
+    if constexpr (C::DMA) {
+      // the slab is a verbatim image: DMA it straight into the other LDS stage (wave = 1 KiB)
+      const float* src = wpk + (size_t)(c0 * NTAP) * A.CoutP;
+      float* dst = smem + (((c0 / CK) & 1) * C::STAGE) + WOFF + wid * 256;
 #pragma unroll
-    for (int q = 0; q < NQW; ++q) {
-      const int row = min(n0 + w_sub + q * RP, Cout - 1);
-      wreg[q] = A.w[row * w_row_stride + wbase];
+      for (int q = 0; q < NQ4; ++q) {
+        const int k = pk_k0 + q * RPQ;
+        if (k < RL) __builtin_amdgcn_global_load_lds(src + (size_t)k * A.CoutP, dst + q * NT * 4, 16, 0, 0);
+      }
+    } else if constexpr (PK) {
+      const float* src = wpk + (size_t)(c0 * NTAP) * A.CoutP;
+#pragma unroll
+      for (int q = 0; q < NQ4; ++q) {
+        const int k = min(pk_k0 + q * RPQ, RL - 1);   // tail rows re-copy row RL-1
+        wreg4[q] = *reinterpret_cast<const f32x4*>(src + (size_t)k * A.CoutP);
+      }
+    } else {
+      const int wbase = min(c0 + w_c, Cin - 1) * w_ch_stride + w_tap;
+#pragma unroll
+      for (int q = 0; q < NQW; ++q) {
+        const int row = min(n0 + w_sub + q * RP, Cout - 1);
+        wreg[q] = A.w[row * w_row_stride + wbase];
+      }
     }
   };
   auto store_chunk = [&](float* st, int c0) {
@@ -171,12 +222,21 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
       const bool ok = ((pvalid >> q) & 1u) && (c0 + c) < Cin;
       st[(e < NP) ? e : DUMMY] = ok ? preg[q] : 0.f;
     }
-    const bool cok = wrow_ok && (c0 + w_c) < Cin;
+    if constexpr (C::DMA) {
+    } else if constexpr (PK) {
 #pragma unroll
-    for (int q = 0; q < NQW; ++q) {
-      const int co_l = w_sub + q * RP;
-      const bool ok = cok && co_l < TN && (n0 + co_l) < Cout;
-      st[(wrow_ok && co_l < TN) ? NP + co_l * WS + w_r : DUMMY] = ok ? wreg[q] : 0.f;
+      for (int q = 0; q < NQ4; ++q) {
+        const int k = min(pk_k0 + q * RPQ, RL - 1);
+        *reinterpret_cast<f32x4*>(st + WOFF + k * TN + 4 * pk_c4) = wreg4[q];
+      }
+    } else {
+      const bool cok = wrow_ok && (c0 + w_c) < Cin;
+#pragma unroll
+      for (int q = 0; q < NQW; ++q) {
+        const int co_l = w_sub + q * RP;
+        const bool ok = cok && co_l < TN && (n0 + co_l) < Cout;
+        st[(wrow_ok && co_l < TN) ? WOFF + co_l * WS + w_r : DUMMY] = ok ? wreg[q] : 0.f;
+      }
     }
   };
 
@@ -184,7 +244,9 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
   int base_w[FC], base_p[FP];
   constexpr int CPG = CK / 2 / C::KS;   // channel pairs per K group
 #pragma unroll
-  for (int g = 0; g < FC; ++g) base_w[g] = NP + ((wc * FC + g) * 32 + l32) * WS + h * NTAP + kg * CPG * 2 * NTAP;
+  for (int g = 0; g < FC; ++g)
+    base_w[g] = PK ? WOFF + (h * NTAP + kg * CPG * 2 * NTAP) * TN + (wc * FC + g) * 32 + l32
+                   : WOFF + ((wc * FC + g) * 32 + l32) * WS + h * NTAP + kg * CPG * 2 * NTAP;
 #pragma unroll
   for (int f = 0; f < FP; ++f) {
     const int m = (wp * FP + f) * 32 + l32;
@@ -217,7 +279,7 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
       const int ro = (MODE == MODE_FWD) ? t / 5 : NTMAX - 1 - t / NTW;   // patch row / col offset of the tap
       const int cof = (MODE == MODE_FWD) ? t % 5 : NTMAX - 1 - t % NTW;
 #pragma unroll
-      for (int g = 0; g < FC; ++g) a[g] = st[base_w[g] + cp * 2 * NTAP + t];
+      for (int g = 0; g < FC; ++g) a[g] = st[base_w[g] + (cp * 2 * NTAP + t) * (PK ? TN : 1)];
 #pragma unroll
       for (int f = 0; f < FP; ++f) b[f] = st[base_p[f] + (2 * cp * PH + ro) * PWP + cof];
     };
@@ -288,7 +350,7 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
 
 template <class C>
 __global__ __launch_bounds__(C::NT, C::MINW) void conv5x5_igemm_kernel(Args A) {
-  __shared__ float smem[2 * C::STAGE];
+  __shared__ __attribute__((aligned(16))) float smem[2 * C::STAGE];
   int bid = blockIdx.x;
   if constexpr (C::NCLS == 1) {
     igemm_body<C, 0, 0>(A, smem, bid);
@@ -310,6 +372,7 @@ int launch(const float* x, const float* w, const float* bias, float* y, int B, i
   Args A;
   A.x = x; A.w = w; A.bias = bias; A.y = y;
   A.B = B; A.Cin = Cin; A.XH = XH; A.XW = XW; A.Cout = Cout;
+  A.CinP = packed_cin(Cin); A.CoutP = packed_cout(Cout);
   int tsh, tsw;  // tile-space extent
   if (C::MODE == MODE_FWD) {
     A.YH = (XH - 1) / C::S + 1; A.YW = (XW - 1) / C::S + 1;
@@ -338,12 +401,12 @@ int launch(const float* x, const float* w, const float* bias, float* y, int B, i
 //   variant 2:  64 px x  64 cout, 4 waves              variant 6: 128 px x 32 cout, 4 waves (thin)
 //   variant 3: 128 px x  64 cout, 4 waves              variant 7: 256 px x 32 cout, 8 waves (thin)
 // K chunk: 2 channels (forward / stride 1) or 4 (stride-2 transposed); 4 / 8 for the K-split form.
-template <int MODE, int S, int WIDTH, int VAR>
+template <int MODE, int S, int WIDTH, int VAR, bool PK>
 struct Pick;
-#define VG_PICK(WIDTH, VAR, NB, TH, TW, TN, WC, WP, CKF, CKT, KS)                                         \
-  template <int MODE, int S>                                                                              \
-  struct Pick<MODE, S, WIDTH, VAR> {                                                                      \
-    using type = Cfg<MODE, S, NB, TH, TW, TN, WC, WP, ((MODE == MODE_FWD || S == 1) ? CKF : CKT), 2, KS>; \
+#define VG_PICK(WIDTH, VAR, NB, TH, TW, TN, WC, WP, CKF, CKT, KS)                                             \
+  template <int MODE, int S, bool PK>                                                                         \
+  struct Pick<MODE, S, WIDTH, VAR, PK> {                                                                      \
+    using type = Cfg<MODE, S, NB, TH, TW, TN, WC, WP, ((MODE == MODE_FWD || S == 1) ? CKF : CKT), 2, KS, PK>; \
   };
 //       W  V NB TH TW   TN WC WP CKF CKT KS
 VG_PICK(32, 0, 1, 4, 32, 128, 2, 2, 2, 4, 1)
@@ -376,24 +439,24 @@ constexpr int NVAR = 8;
 
 int g_tile_override[2] = {-1, -1};  // diagnostics only (vg_debug_set_conv_tile)
 
-template <int MODE, int S, int WIDTH>
+template <int MODE, int S, int WIDTH, bool PK>
 int launch_var(int var, const float* x, const float* w, const float* bias, float* y, int B, int Cin, int XH,
                int XW, int Cout, hipStream_t st) {
   switch (var) {
-    case 0: return launch<typename Pick<MODE, S, WIDTH, 0>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    case 1: return launch<typename Pick<MODE, S, WIDTH, 1>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    case 2: return launch<typename Pick<MODE, S, WIDTH, 2>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    case 3: return launch<typename Pick<MODE, S, WIDTH, 3>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    case 4: return launch<typename Pick<MODE, S, WIDTH, 4>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    case 5: return launch<typename Pick<MODE, S, WIDTH, 5>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    case 6: return launch<typename Pick<MODE, S, WIDTH, 6>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    default: return launch<typename Pick<MODE, S, WIDTH, 7>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    case 0: return launch<typename Pick<MODE, S, WIDTH, 0, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    case 1: return launch<typename Pick<MODE, S, WIDTH, 1, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    case 2: return launch<typename Pick<MODE, S, WIDTH, 2, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    case 3: return launch<typename Pick<MODE, S, WIDTH, 3, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    case 4: return launch<typename Pick<MODE, S, WIDTH, 4, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    case 5: return launch<typename Pick<MODE, S, WIDTH, 5, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    case 6: return launch<typename Pick<MODE, S, WIDTH, 6, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    default: return launch<typename Pick<MODE, S, WIDTH, 7, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
   }
 }
 
 // Tile choice: widest pixel row the tile space supports; cout tile to fit Cout; smaller tiles
 // when the big ones would leave CUs idle (256 CUs x 2 resident workgroups).
-template <int MODE, int S>
+template <int MODE, int S, bool PK>
 int dispatch(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int XH, int XW,
              int Cout, hipStream_t st) {
   const int tsw = (MODE == MODE_FWD) ? (XW - 1) / S + 1 : XW;
@@ -412,15 +475,47 @@ int dispatch(const float* x, const float* w, const float* bias, float* y, int B,
     if (px256 * cdiv(Cout, 128) >= 256 && Cout > 64) var = 4;
     else if (px256 * cdiv(Cout, 64) >= 256) var = 1;
     else var = 5;
-  } else {
+  } else if (!PK) {
     if (px256 * cdiv(Cout, 64) * ncls >= 1024) var = 1;
     else var = (2 * px256 * cdiv(Cout, 64) * ncls < 768) ? 5 : 3;
+  } else {
+    // packed filters make the 128-cout tile's slab copy cheap: 128 px x 128 cout where it fills the chip
+    if (Cout > 64 && 2 * px256 * cdiv(Cout, 128) * ncls >= 1024) var = 0;
+    else if (px256 * cdiv(Cout, 64) * ncls >= 1024) var = 1;
+    else var = (2 * px256 * cdiv(Cout, 64) * ncls < 768) ? 2 : 3;
   }
   const int ov = g_tile_override[MODE];
   const int use = (ov >= 0 && ov < NVAR) ? ov : var;
-  if (width == 32) return launch_var<MODE, S, 32>(use, x, w, bias, y, B, Cin, XH, XW, Cout, st);
-  if (width == 16) return launch_var<MODE, S, 16>(use, x, w, bias, y, B, Cin, XH, XW, Cout, st);
-  return launch_var<MODE, S, 8>(use, x, w, bias, y, B, Cin, XH, XW, Cout, st);
+  if (width == 32) return launch_var<MODE, S, 32, PK>(use, x, w, bias, y, B, Cin, XH, XW, Cout, st);
+  if (width == 16) return launch_var<MODE, S, 16, PK>(use, x, w, bias, y, B, Cin, XH, XW, Cout, st);
+  return launch_var<MODE, S, 8, PK>(use, x, w, bias, y, B, Cin, XH, XW, Cout, st);
+}
+
+// ---- filter pre-pack: [class][ci][tap][CoutP], zero padded to CinP x CoutP.  One workgroup
+// transposes the 25 taps of 64 output channels of one input channel through LDS.
+template <int TRANSPOSED>
+__global__ __launch_bounds__(256) void pack_filter_kernel(const float* __restrict__ w, float* __restrict__ p,
+                                                          int Cout, int Cin, int CinP, int CoutP, int S) {
+  __shared__ float t[64 * 25 + 1];
+  const int ci = blockIdx.x, co0 = blockIdx.y * 64, tid = threadIdx.x;
+  for (int e = tid; e < 64 * 25; e += 256) {
+    const int col = e / 25, tap = e - col * 25, co = co0 + col;
+    float v = 0.f;
+    if (ci < Cin && co < Cout)
+      v = TRANSPOSED ? w[((size_t)ci * Cout + co) * 25 + tap] : w[((size_t)co * Cin + ci) * 25 + tap];
+    t[e] = v;
+  }
+  __syncthreads();
+  // packed position of tap (kh, kw): class (kh % S, kw % S), index (kh / S) * ntw + kw / S
+  for (int e = tid; e < 64 * 25; e += 256) {
+    const int tap = e / 64, col = e % 64;
+    const int kh = tap / 5, kw = tap % 5;
+    const int R = kh % S, SS = kw % S;
+    const int ntw = (5 - SS + S - 1) / S, nth = (5 - R + S - 1) / S;
+    const int tb = taps_before(S, R, SS);
+    const size_t row = (size_t)tb * CinP + (size_t)ci * (nth * ntw) + (kh / S) * ntw + kw / S;
+    p[row * CoutP + co0 + col] = t[col * 25 + tap];
+  }
 }
 
 }  // namespace
@@ -431,22 +526,65 @@ extern "C" int vg_debug_set_conv_tile(int mode, int variant) {
   return 0;
 }
 
+extern "C" size_t vg_conv5x5_packed_floats(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0) return 0;
+  return (size_t)25 * packed_cin(Cin) * packed_cout(Cout);
+}
+
+extern "C" int vg_conv5x5_pack(const float* w, float* packed, int Cout, int Cin, int transposed, int stride,
+                               void* stream) {
+  if (!w || !packed || Cout <= 0 || Cin <= 0 || (stride != 1 && stride != 2)) return VG_ERR_BAD_ARG;
+  if (((uintptr_t)packed & 15) != 0) return VG_ERR_BAD_ARG;
+  const int CinP = packed_cin(Cin), CoutP = packed_cout(Cout);
+  const dim3 grid((unsigned)CinP, (unsigned)(CoutP / 64));
+  if (CoutP / 64 > 65535) return VG_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (transposed)
+    hipLaunchKernelGGL(pack_filter_kernel<1>, grid, dim3(256), 0, st, w, packed, Cout, Cin, CinP, CoutP, stride);
+  else   // the forward kernel walks all 25 taps as one class
+    hipLaunchKernelGGL(pack_filter_kernel<0>, grid, dim3(256), 0, st, w, packed, Cout, Cin, CinP, CoutP, 1);
+  VG_CHECK_LAUNCH();
+  return 0;
+}
+
+static int conv_args_ok(const float* x, const float* w, float* y, int B, int Cin, int H, int W, int Cout,
+                        int stride) {
+  if (!x || !w || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+  return stride == 1 || stride == 2;
+}
+
 extern "C" int vg_conv5x5_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin,
                               int H, int W, int Cout, int stride, void* stream) {
-  if (!x || !w || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return VG_ERR_BAD_ARG;
-  if (stride != 1 && stride != 2) return VG_ERR_BAD_ARG;
+  if (!conv_args_ok(x, w, y, B, Cin, H, W, Cout, stride)) return VG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (stride == 2) return dispatch<MODE_FWD, 2>(x, w, bias, y, B, Cin, H, W, Cout, st);
-  return dispatch<MODE_FWD, 1>(x, w, bias, y, B, Cin, H, W, Cout, st);
+  if (stride == 2) return dispatch<MODE_FWD, 2, false>(x, w, bias, y, B, Cin, H, W, Cout, st);
+  return dispatch<MODE_FWD, 1, false>(x, w, bias, y, B, Cin, H, W, Cout, st);
+}
+
+extern "C" int vg_conv5x5_fwd_packed(const float* x, const float* packed, const float* bias, float* y, int B,
+                                     int Cin, int H, int W, int Cout, int stride, void* stream) {
+  if (!conv_args_ok(x, packed, y, B, Cin, H, W, Cout, stride) || ((uintptr_t)packed & 15) != 0)
+    return VG_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (stride == 2) return dispatch<MODE_FWD, 2, true>(x, packed, bias, y, B, Cin, H, W, Cout, st);
+  return dispatch<MODE_FWD, 1, true>(x, packed, bias, y, B, Cin, H, W, Cout, st);
 }
 
 extern "C" int vg_convT5x5_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin,
                                int H, int W, int Cout, int stride, void* stream) {
-  if (!x || !w || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return VG_ERR_BAD_ARG;
-  if (stride != 1 && stride != 2) return VG_ERR_BAD_ARG;
+  if (!conv_args_ok(x, w, y, B, Cin, H, W, Cout, stride)) return VG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (stride == 2) return dispatch<MODE_TR, 2>(x, w, bias, y, B, Cin, H, W, Cout, st);
+  if (stride == 2) return dispatch<MODE_TR, 2, false>(x, w, bias, y, B, Cin, H, W, Cout, st);
   // <= 4 output channels: direct VALU kernel (an MFMA tile would be 3/32 full)
   if (Cout <= 4 && g_tile_override[MODE_TR] < 0) return vg_internal_convT_s1_thin(x, w, bias, y, B, Cin, H, W, Cout, st);
-  return dispatch<MODE_TR, 1>(x, w, bias, y, B, Cin, H, W, Cout, st);
+  return dispatch<MODE_TR, 1, false>(x, w, bias, y, B, Cin, H, W, Cout, st);
+}
+
+extern "C" int vg_convT5x5_fwd_packed(const float* x, const float* packed, const float* bias, float* y, int B,
+                                      int Cin, int H, int W, int Cout, int stride, void* stream) {
+  if (!conv_args_ok(x, packed, y, B, Cin, H, W, Cout, stride) || ((uintptr_t)packed & 15) != 0)
+    return VG_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (stride == 2) return dispatch<MODE_TR, 2, true>(x, packed, bias, y, B, Cin, H, W, Cout, st);
+  return dispatch<MODE_TR, 1, true>(x, packed, bias, y, B, Cin, H, W, Cout, st);
 }

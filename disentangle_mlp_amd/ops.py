@@ -93,6 +93,70 @@ def reserve_workspace(nbytes, device):
 
 
 # ---------------------------------------------------------------- convolutions
+# Packed filters (vg_conv5x5_pack): the implicit-GEMM kernels read the filter as
+# [class][ci][tap][cout].  Outside a `packed_filter_scope` every launch re-packs its weight
+# (a few microseconds); inside one -- the trainer opens it around an iteration, where it
+# alone decides when weights change -- a pack is reused until `invalidate_packed_filters()`.
+USE_PACKED_FILTERS = True
+_pack_scope_depth = 0
+_pack_cache = {}      # (data_ptr, transposed, stride, shape) -> [valid, version, packed tensor]
+_pack_scratch = {}    # (device, stream, numel) -> tensor, for un-cached packs
+
+
+class packed_filter_scope:
+    """Within the scope packed filters are cached per weight storage; the owner of the scope
+    promises to call `invalidate_packed_filters()` after every in-place weight update."""
+
+    def __enter__(self):
+        global _pack_scope_depth
+        if _pack_scope_depth == 0:
+            invalidate_packed_filters()
+        _pack_scope_depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _pack_scope_depth
+        _pack_scope_depth -= 1
+        if _pack_scope_depth == 0:
+            invalidate_packed_filters()
+        return False
+
+
+def invalidate_packed_filters(params=None):
+    """Drop cached packs -- all of them, or those of the given weight tensors."""
+    if params is None:
+        for ent in _pack_cache.values():
+            ent[0] = False
+        return
+    ptrs = {p.data_ptr() for p in params if p.dim() == 4}
+    for key, ent in _pack_cache.items():
+        if key[0] in ptrs:
+            ent[0] = False
+
+
+def _packed_filter(lib, w, cout, cin, transposed, stride):
+    n = lib.vg_conv5x5_packed_floats(cout, cin)
+    if _pack_scope_depth > 0:
+        key = (w.data_ptr(), transposed, stride, tuple(w.shape))
+        ent = _pack_cache.get(key)
+        if ent is not None and ent[0] and ent[1] == w._version:
+            return ent[2]
+        if ent is None:
+            ent = _pack_cache[key] = [False, -1, torch.empty(n, dtype=torch.float32, device=w.device)]
+        buf = ent[2]
+    else:
+        ent = None
+        skey = (w.device.index, _stream(), n)
+        buf = _pack_scratch.get(skey)
+        if buf is None:
+            buf = _pack_scratch[skey] = torch.empty(n, dtype=torch.float32, device=w.device)
+    check(lib.vg_conv5x5_pack(w.data_ptr(), buf.data_ptr(), cout, cin, transposed, stride, _stream()),
+          "vg_conv5x5_pack")
+    if ent is not None:
+        ent[0], ent[1] = True, w._version
+    return buf
+
+
 def conv5x5_fwd(x, w, bias, stride):
     lib = _lib.load()
     _req(x, "x"), _req(w, "w")
@@ -104,6 +168,12 @@ def conv5x5_fwd(x, w, bias, stride):
         _req(bias, "bias")
     OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
     y = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
+    if USE_PACKED_FILTERS:
+        pk = _packed_filter(lib, w, Cout, Cin, 0, stride)
+        with _timed(("conv_fwd", B, Cin, H, W, Cout, stride)):
+            check(lib.vg_conv5x5_fwd_packed(x.data_ptr(), pk.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W,
+                                            Cout, stride, _stream()), "vg_conv5x5_fwd_packed")
+        return y
     with _timed(("conv_fwd", B, Cin, H, W, Cout, stride)):
         check(lib.vg_conv5x5_fwd(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W, Cout,
                                  stride, _stream()), "vg_conv5x5_fwd")
@@ -121,6 +191,13 @@ def convT5x5_fwd(x, w, bias, stride):
     if bias is not None:
         _req(bias, "bias")
     y = torch.empty((B, Cout, H * stride, W * stride), dtype=torch.float32, device=x.device)
+    # stride 1 with <= 4 output channels runs the direct VALU kernel on the plain layout
+    if USE_PACKED_FILTERS and not (stride == 1 and Cout <= 4):
+        pk = _packed_filter(lib, w, Cout, Cin, 1, stride)
+        with _timed(("convT_fwd", B, Cin, H, W, Cout, stride)):
+            check(lib.vg_convT5x5_fwd_packed(x.data_ptr(), pk.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W,
+                                             Cout, stride, _stream()), "vg_convT5x5_fwd_packed")
+        return y
     with _timed(("convT_fwd", B, Cin, H, W, Cout, stride)):
         check(lib.vg_convT5x5_fwd(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W, Cout,
                                   stride, _stream()), "vg_convT5x5_fwd")

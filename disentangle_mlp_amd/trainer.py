@@ -29,6 +29,7 @@ import torch.distributed as dist
 from torch import optim
 
 from . import functional as F
+from . import ops
 from .model import VAE, Discriminator_celeba, Generator_celeba, weights_init
 
 
@@ -184,6 +185,8 @@ class BetaVAEGANTrainer:
         self.netEG.train()
         self.netD.train()
         self.iteration = 0
+        self._eg_params = [p for p in self.netEG.parameters() if p.dim() == 4]   # convolution filters
+        self._d_params = [p for p in self.netD.parameters() if p.dim() == 4]
 
     # -- gradient plumbing ------------------------------------------------------
     def _zero(self, net, flat):
@@ -203,6 +206,11 @@ class BetaVAEGANTrainer:
     # -- one iteration ------------------------------------------------------------
     def step(self, data, noise=None, eps2=None, eps3=None, real_label=0.9, fake_label=0.1,
              global_batch: Optional[int] = None, grad_hook=None) -> Dict[str, torch.Tensor]:
+        # weights change only at the three optimizer steps below: packed filters are reused between them
+        with ops.packed_filter_scope():
+            return self._step(data, noise, eps2, eps3, real_label, fake_label, global_batch, grad_hook)
+
+    def _step(self, data, noise, eps2, eps3, real_label, fake_label, global_batch, grad_hook):
         """data (B,3,64,64) in [-1,1]; noise / eps2 / eps3 (B, n_hidden) ~ N(0,1) are drawn on
         the device when omitted (new_betavaegan.py:111, model.py:534).  Labels are the
         per-iteration scalars of :89-90.  Returns device scalars (no sync).
@@ -231,6 +239,7 @@ class BetaVAEGANTrainer:
         if grad_hook:
             grad_hook("D", netD)
         self.optimizerD.step()
+        ops.invalidate_packed_filters(self._d_params)
         out["errD_real"], out["errD_fake"] = err_real.detach(), err_fake.detach()
         out["D_x_sum"] = p_real.detach().sum()
 
@@ -252,6 +261,7 @@ class BetaVAEGANTrainer:
         if grad_hook:
             grad_hook("EG2", netEG)
         self.optimizerEG.step()
+        ops.invalidate_packed_filters(self._eg_params)
         out.update(errG_fake=err_g_fake.detach(), errG_recon=err_g_rec.detach(), sim=sim.detach(),
                    mse_dec=mse2.detach())
 
@@ -264,6 +274,7 @@ class BetaVAEGANTrainer:
         if grad_hook:
             grad_hook("EG3", netEG)
         self.optimizerEG.step()
+        ops.invalidate_packed_filters(self._eg_params)
         out.update(kld=kld.detach(), mse_enc=mse3.detach())
         self.iteration += 1
         return out
@@ -315,6 +326,10 @@ class VAETrainer:
         self.model.train()
 
     def step(self, data, eps=None):
+        with ops.packed_filter_scope():       # one optimizer step at the end: packs live for the iteration
+            return self._step(data, eps)
+
+    def _step(self, data, eps):
         if self.flat is not None:
             self.flat.zero_and_attach()
         else:
@@ -350,6 +365,10 @@ class GANTrainer:
         self.netD.train()
 
     def step(self, data, noise=None, real_label=0.9, fake_label=0.1):
+        with ops.packed_filter_scope():
+            return self._step(data, noise, real_label, fake_label)
+
+    def _step(self, data, noise, real_label, fake_label):
         B = data.size(0)
         if noise is None:
             noise = torch.randn(B, self.opt.n_hidden, device=data.device)
@@ -361,6 +380,7 @@ class GANTrainer:
         err_fake = F.bce_loss(p_fake, fake_label)
         torch.autograd.backward([err_real, err_fake])
         self.optimizerD.step()
+        ops.invalidate_packed_filters()
         self.netG.zero_grad(set_to_none=True)
         for p in self.netD.parameters():
             p.requires_grad_(False)

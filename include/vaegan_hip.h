@@ -62,6 +62,24 @@ int vg_conv5x5_fwd(const float* x, const float* w, const float* bias, float* y,
 int vg_convT5x5_fwd(const float* x, const float* w, const float* bias, float* y,
                     int B, int Cin, int H, int W, int Cout, int stride, void* stream);
 
+/* Pre-packed filters.  The implicit-GEMM kernels run fastest when the filter slab of a K
+ * chunk is a verbatim 16-byte copy: vg_conv5x5_pack rewrites a weight tensor once per
+ * weight version into [parity class][ci][tap][cout] (cout innermost, zero padded to a
+ * multiple of 128 output / 8 input channels), vg_conv5x5_fwd_packed /
+ * vg_convT5x5_fwd_packed consume it.  On the same tile variant the results are bit-identical
+ * to the plain entry points (same K order); the tile heuristics of the two may differ.
+ *   transposed = 0: w is [Cout,Cin,5,5], for vg_conv5x5_fwd_packed (stride ignored);
+ *   transposed = 1: w is [Cin,Cout,5,5], for vg_convT5x5_fwd_packed with the SAME stride
+ *                   (the stride-2 kernel walks the 4 output-parity classes separately).
+ * `packed` holds vg_conv5x5_packed_floats(Cout, Cin) floats, 16-byte aligned. */
+size_t vg_conv5x5_packed_floats(int Cout, int Cin);
+int vg_conv5x5_pack(const float* w, float* packed, int Cout, int Cin, int transposed, int stride,
+                    void* stream);
+int vg_conv5x5_fwd_packed(const float* x, const float* packed, const float* bias, float* y,
+                          int B, int Cin, int H, int W, int Cout, int stride, void* stream);
+int vg_convT5x5_fwd_packed(const float* x, const float* packed, const float* bias, float* y,
+                           int B, int Cin, int H, int W, int Cout, int stride, void* stream);
+
 /* dw[Cout,Cin,5,5] = sum_{b,oh,ow} gy[b,co,oh,ow] * x[b,ci,s*oh+kh-2,s*ow+kw-2].
  * Weight gradient of nn.Conv2d (autograd of model.py:450...; new_betavaegan.py:103,121)
  * and, with the roles swapped (x := gy_T, gy := x_T), of nn.ConvTranspose2d.

@@ -27,6 +27,11 @@ def timeit(fn, n=10):
 
 
 variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2, 3, 4, 5]
+# argv[2]: "p" packed filters (cached: the pack is outside the timed launches), "u" plain layout
+ops.USE_PACKED_FILTERS = not (len(sys.argv) > 2 and sys.argv[2] == "u")
+print("packed filters:", ops.USE_PACKED_FILTERS, flush=True)
+scope = ops.packed_filter_scope()
+scope.__enter__()
 for name, cin, cout, h in FWD:
     x = torch.randn(B, cin, h, h, device="cuda")
     w = torch.randn(cout, cin, 5, 5, device="cuda") * 0.02

@@ -341,3 +341,71 @@ def test_conv_random_shapes(H):
         wt = 0.2 * _rand(Cin, Cout, 5, 5, seed=500 + case)
         assert_close(H.convT5x5_fwd(x.cuda(), wt.cuda(), b.cuda(), stride), O.convT5x5(x, wt, b, stride), 3e-6,
                      tag + " convT")
+
+
+# ------------------------------------------------------------------ packed filters
+@pytest.mark.parametrize("B,Cin,Cout,Hs,Ws,stride", [
+    (3, 3, 32, 16, 16, 1), (2, 32, 128, 32, 32, 2), (2, 5, 130, 9, 13, 2), (2, 70, 33, 8, 8, 1),
+    (1, 256, 256, 8, 8, 2)])
+def test_packed_filters_bit_identical(H, B, Cin, Cout, Hs, Ws, stride):
+    """vg_conv5x5_fwd_packed / vg_convT5x5_fwd_packed walk K in the same order as the plain
+    entry points: results must be bit-identical on every tile variant."""
+    from disentangle_mlp_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Cin, Hs, Ws, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 5, 5, generator=g) * 0.05).cuda()
+    wt = (torch.randn(Cin, Cout, 5, 5, generator=g) * 0.05).cuda()
+    bias = torch.randn(Cout, generator=g).cuda()
+    try:
+        for variant in list(range(8)) + [-1]:
+            lib.vg_debug_set_conv_tile(0, variant)
+            lib.vg_debug_set_conv_tile(1, variant)
+            H.USE_PACKED_FILTERS = True
+            yp, ytp = H.conv5x5_fwd(x, w, bias, stride), H.convT5x5_fwd(x, wt, bias, stride)
+            H.USE_PACKED_FILTERS = False
+            yu, ytu = H.conv5x5_fwd(x, w, bias, stride), H.convT5x5_fwd(x, wt, bias, stride)
+            if variant >= 0:
+                assert torch.equal(yp, yu), f"conv variant {variant}"
+                assert torch.equal(ytp, ytu), f"convT variant {variant}"
+            else:   # the heuristics may pick different tiles (K-split or not): summation order only
+                assert_close(yp, yu.cpu(), 1e-6, "conv heuristic tile")
+                assert_close(ytp, ytu.cpu(), 1e-6, "convT heuristic tile")
+    finally:
+        H.USE_PACKED_FILTERS = True
+        lib.vg_debug_set_conv_tile(0, -1)
+        lib.vg_debug_set_conv_tile(1, -1)
+
+
+def test_packed_filter_cache_scope(H):
+    """Outside a scope every launch re-packs; inside, a pack is reused until the weight's version
+    changes or invalidate_packed_filters() is called (the trainer's contract)."""
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 16, 8, 8, generator=g).cuda()
+    w = (torch.randn(32, 16, 5, 5, generator=g) * 0.1).cuda()
+    y0 = H.conv5x5_fwd(x, w, None, 1)
+    w.data.mul_(2.0)                                   # no version bump, no scope: still seen
+    assert torch.equal(H.conv5x5_fwd(x, w, None, 1), 2 * y0)
+    with H.packed_filter_scope():
+        y1 = H.conv5x5_fwd(x, w, None, 1)
+        assert torch.equal(y1, 2 * y0)
+        w.mul_(2.0)                                    # in-place update bumps the version
+        assert torch.equal(H.conv5x5_fwd(x, w, None, 1), 4 * y0)
+        w.data.mul_(0.5)                               # invisible to the version counter ...
+        assert torch.equal(H.conv5x5_fwd(x, w, None, 1), 4 * y0)
+        H.invalidate_packed_filters([w])               # ... until the owner says so
+        assert torch.equal(H.conv5x5_fwd(x, w, None, 1), 2 * y0)
+    w.data.mul_(0.5)
+    assert torch.equal(H.conv5x5_fwd(x, w, None, 1), y0)   # leaving the scope dropped the cache
+
+
+def test_packed_filter_bad_args(H):
+    from disentangle_mlp_amd import _lib
+    lib = _lib.load()
+    w = torch.zeros(8, 4, 5, 5).cuda()
+    pk = torch.zeros(lib.vg_conv5x5_packed_floats(8, 4) + 4).cuda()
+    assert lib.vg_conv5x5_packed_floats(8, 4) == 25 * 8 * 128
+    assert lib.vg_conv5x5_packed_floats(0, 4) == 0
+    assert lib.vg_conv5x5_pack(w.data_ptr(), pk.data_ptr() + 4, 8, 4, 0, 1, 0) == -1   # misaligned
+    assert lib.vg_conv5x5_pack(w.data_ptr(), pk.data_ptr(), 8, 4, 0, 3, 0) == -1       # stride
+    assert lib.vg_conv5x5_pack(0, pk.data_ptr(), 8, 4, 0, 1, 0) == -1
