@@ -1,0 +1,210 @@
+"""Input pipeline: ``get_data_loader(opt)`` of /root/reference/dataloader/dataset.py:14-50 for the
+celebA branch (:37-50), re-designed for a GPU with 288 GB of HBM.
+
+The reference decodes and resizes every JPEG again in every epoch (PIL, 4 worker processes: a
+few thousand images/s -- one MI355X trains at 4,400, a node at ~30,000).  Here the dataset is
+decoded and resized ONCE into a uint8 ``[N][H][W][3]`` cache file (CelebA at 64x64: 2.5 GB),
+the cache lives in HBM, and a batch is one kernel: gather the shuffled rows, ToTensor +
+Normalize(0.5, 0.5) -> fp32 NCHW (``vg_u8_gather_normalize``, bit-identical to the CPU
+transforms).  The epoch's permutation is uploaded once; the step loop has no host traffic.
+
+Kept from the reference: the ``get_data_loader(opt) -> (train, val, test)`` signature and the
+``opt`` fields it reads, ``for data, labels in loader``, ``len(loader)``, ``loader.dataset``,
+ImageFolder's sample order and class indices, DataLoader's batch order for ``shuffle=False`` and
+its RNG consumption + permutation for ``shuffle=True`` (same ``torch.manual_seed`` => same
+batches as ``torch.utils.data.DataLoader``), a short last batch (``drop_last=False``).
+Under data parallelism every rank draws the same permutation and takes its contiguous slice of
+each global batch -- what ``nn.DataParallel``'s scatter hands to each GPU.
+"""
+import hashlib
+import json
+import math
+import os
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+import torch
+
+from . import ops
+
+IMG_EXTENSIONS = (".jpg", ".jpeg", ".png", ".ppm", ".bmp", ".pgm", ".tif")
+
+
+def list_image_folder(root):
+    """(classes, [(path, class_index)]) in torchvision ImageFolder order."""
+    if not os.path.isdir(root):
+        raise FileNotFoundError(f"image root {root!r} does not exist")
+    classes = sorted(d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d)))
+    samples = []
+    for ci, cname in enumerate(classes):
+        for dirpath, _, fnames in sorted(os.walk(os.path.join(root, cname))):
+            for fname in sorted(fnames):
+                if fname.lower().endswith(IMG_EXTENSIONS):
+                    samples.append((os.path.join(dirpath, fname), ci))
+    if not samples:
+        raise RuntimeError(f"found 0 images in sub-folders of {root!r}")
+    return classes, samples
+
+
+def _decode_resized(args):
+    path, size = args
+    from PIL import Image
+    with open(path, "rb") as f:
+        img = Image.open(f).convert("RGB")
+    # Resize((s, s)) then CenterCrop(s): the crop of an s x s image is the image
+    return np.asarray(img.resize((size, size), Image.BILINEAR), dtype=np.uint8)
+
+
+def _fingerprint(root, samples, size):
+    h = hashlib.sha1(f"{size}".encode())
+    for path, ci in samples:
+        st = os.stat(path)
+        h.update(f"{os.path.relpath(path, root)}|{ci}|{st.st_size}|{int(st.st_mtime)}\n".encode())
+    return h.hexdigest()
+
+
+def build_image_cache(root, img_size, cache_dir=None, workers=None):
+    """Decode + resize every image of an ImageFolder tree once; returns (images.npy, labels.npy).
+    Re-used when the file list (names, sizes, mtimes) is unchanged."""
+    classes, samples = list_image_folder(root)
+    cache_dir = cache_dir or root
+    tag = hashlib.sha1(os.path.abspath(root).encode()).hexdigest()[:10]
+    base = os.path.join(cache_dir, f".u8cache_{tag}_{img_size}")
+    img_file, lab_file, meta_file = base + "_images.npy", base + "_labels.npy", base + "_meta.json"
+    fp = _fingerprint(root, samples, img_size)
+    if all(os.path.exists(f) for f in (img_file, lab_file, meta_file)):
+        with open(meta_file) as f:
+            if json.load(f).get("fingerprint") == fp:
+                return img_file, lab_file
+    os.makedirs(cache_dir, exist_ok=True)
+    n = len(samples)
+    out = np.lib.format.open_memmap(img_file + ".tmp", mode="w+", dtype=np.uint8, shape=(n, img_size, img_size, 3))
+    jobs = [(p, img_size) for p, _ in samples]
+    workers = workers if workers is not None else min(16, os.cpu_count() or 1)
+    if workers > 1 and n >= 256:
+        with ProcessPoolExecutor(max_workers=workers) as pool:
+            for i, arr in enumerate(pool.map(_decode_resized, jobs, chunksize=64)):
+                out[i] = arr
+    else:
+        for i, job in enumerate(jobs):
+            out[i] = _decode_resized(job)
+    out.flush()
+    del out
+    os.replace(img_file + ".tmp", img_file)
+    np.save(lab_file, np.asarray([ci for _, ci in samples], dtype=np.int64))
+    with open(meta_file, "w") as f:
+        json.dump({"fingerprint": fp, "n": n, "img_size": img_size, "classes": classes}, f)
+    return img_file, lab_file
+
+
+class DeviceImageDataset:
+    """uint8 [N][H][W][C] image cache + int64 labels, resident on the device."""
+
+    def __init__(self, images_u8, labels=None, device="cuda", mean=0.5, std=0.5):
+        if isinstance(images_u8, np.ndarray):
+            images_u8 = torch.from_numpy(np.ascontiguousarray(images_u8))
+        if images_u8.dtype != torch.uint8 or images_u8.dim() != 4:
+            raise ValueError("image cache must be uint8 [N, H, W, C]")
+        self.device = torch.device(device)
+        self.images = self._upload(images_u8)
+        n = self.images.size(0)
+        labels = torch.zeros(n, dtype=torch.int64) if labels is None else torch.as_tensor(np.asarray(labels), dtype=torch.int64)
+        if labels.numel() != n:
+            raise ValueError("labels do not match the image cache")
+        self.labels = labels.to(self.device)
+        self.mean, self.std = float(mean), float(std)
+
+    def _upload(self, t, chunk=1 << 28):
+        # memory-mapped caches are streamed in 256 MiB pieces rather than materialised on the host
+        out = torch.empty(t.shape, dtype=torch.uint8, device=self.device)
+        flat_out, flat_in = out.view(-1), t.reshape(-1)
+        for s in range(0, flat_in.numel(), chunk):
+            flat_out[s:s + chunk].copy_(flat_in[s:s + chunk])
+        return out
+
+    @classmethod
+    def from_files(cls, img_file, lab_file=None, **kw):
+        images = torch.from_numpy(np.load(img_file, mmap_mode="c")   # copy-on-write view: never written, keeps torch quiet)
+        labels = np.load(lab_file) if lab_file else None
+        return cls(images, labels, **kw)
+
+    def __len__(self):
+        return self.images.size(0)
+
+    def batch(self, index):
+        """index: int64 device tensor of image numbers -> (fp32 NCHW batch, labels)."""
+        return ops.u8_gather_normalize(self.images, index, self.mean, self.std), self.labels[index]
+
+
+class DeviceLoader:
+    """Iterates (data, labels) device batches like DataLoader(dataset, batch_size, shuffle)."""
+
+    def __init__(self, dataset, batch_size, shuffle=False, rank=0, world_size=1, generator=None):
+        if batch_size <= 0 or batch_size % world_size:
+            raise ValueError("batch_size must be a positive multiple of world_size")
+        self.dataset, self.batch_size, self.shuffle = dataset, int(batch_size), bool(shuffle)
+        self.rank, self.world_size, self.generator = int(rank), int(world_size), generator
+
+    def __len__(self):
+        return math.ceil(len(self.dataset) / self.batch_size)
+
+    def epoch_order(self):
+        """Sample order of one epoch, consuming the RNG exactly like iter(DataLoader(...)):
+        one int64 draw for the iterator's base seed, then -- when shuffling -- RandomSampler's
+        seed draw and torch.randperm on a private generator."""
+        n = len(self.dataset)
+        torch.empty((), dtype=torch.int64).random_(generator=self.generator)       # _base_seed
+        if not self.shuffle:
+            return torch.arange(n, dtype=torch.int64)
+        if self.generator is None:
+            g = torch.Generator()
+            g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
+        else:
+            g = self.generator
+        return torch.randperm(n, generator=g)
+
+    def index_batches(self, order):
+        """This rank's slice of every global batch of `order` (a 1-D index tensor)."""
+        n, gb, local = order.numel(), self.batch_size, self.batch_size // self.world_size
+        for start in range(0, n, gb):
+            chunk = order[start:start + gb]
+            if self.world_size > 1:                              # DataParallel-style scatter of the batch
+                per = local if chunk.numel() == gb else math.ceil(chunk.numel() / self.world_size)
+                if per * (self.world_size - 1) >= chunk.numel():
+                    break       # a tail too short to give every rank a sample: dropped on ALL ranks (collectives stay matched)
+                chunk = chunk[self.rank * per:(self.rank + 1) * per]
+            yield chunk
+
+    def __iter__(self):
+        order = self.epoch_order().to(self.dataset.device)      # one upload per epoch
+        for index in self.index_batches(order):
+            yield self.dataset.batch(index)
+
+
+def _dist_info():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def get_data_loader(opt):
+    """(train_loader, val_loader, test_loader) -- dataset.py:14-50, celebA / celebA_reduced branch.
+    Reads opt.dataset, opt.img_size, opt.image_root_{train,val,test}, opt.batch_size_{train,val,test};
+    opt.num_workers sizes the one-off cache build; optional opt.cache_dir, opt.device."""
+    if opt.dataset not in ("celebA", "celebA_reduced"):
+        raise NotImplementedError(f"dataset {opt.dataset!r}: only the celebA branch of the reference's "
+                                  "get_data_loader is on the accelerated path")
+    device = getattr(opt, "device", "cuda")
+    cache_dir = getattr(opt, "cache_dir", None)
+    workers = getattr(opt, "num_workers", None) or None
+    rank, world = _dist_info()
+    loaders = []
+    for split, shuffle in (("train", True), ("val", False), ("test", False)):
+        root = getattr(opt, f"image_root_{split}")
+        img_file, lab_file = build_image_cache(root, opt.img_size, cache_dir, workers)
+        ds = DeviceImageDataset.from_files(img_file, lab_file, device=device, mean=0.5, std=0.5)
+        loaders.append(DeviceLoader(ds, getattr(opt, f"batch_size_{split}"), shuffle=shuffle,
+                                    rank=rank if split == "train" else 0,
+                                    world_size=world if split == "train" else 1))
+    return tuple(loaders)

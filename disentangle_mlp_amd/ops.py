@@ -344,3 +344,54 @@ def bce_loss(p, target, divisor=None, gscale=1.0, want_grad=True):
     check(lib.vg_bce_loss(p.data_ptr(), float(target), loss.data_ptr(), _ptr(gp), B,
                           float(divisor if divisor is not None else B), float(gscale), _stream()), "vg_bce_loss")
     return loss, gp
+
+
+# ---------------------------------------------------------------- image I/O
+def u8_gather_normalize(images_u8, index, mean=0.5, std=0.5):
+    """images_u8 [N,H,W,C] uint8 (device), index int64 (device) -> fp32 [B,C,H,W] =
+    (u8 / 255 - mean) / std  (ToTensor + Normalize, dataset.py:37-43)."""
+    lib = _lib.load()
+    if not (isinstance(images_u8, torch.Tensor) and images_u8.is_cuda and images_u8.dtype == torch.uint8
+            and images_u8.dim() == 4 and images_u8.is_contiguous()):
+        raise RuntimeError("u8_gather_normalize: image cache must be a contiguous CUDA/ROCm uint8 [N,H,W,C] tensor")
+    if not (isinstance(index, torch.Tensor) and index.is_cuda and index.dtype == torch.int64 and index.dim() == 1):
+        raise RuntimeError("u8_gather_normalize: index must be a 1-D CUDA/ROCm int64 tensor")
+    index = index.contiguous()
+    N, H, W, C = images_u8.shape
+    B = index.numel()
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=images_u8.device)
+    for s in range(0, B, 65535):                      # grid.y limit
+        n = min(65535, B - s)
+        check(lib.vg_u8_gather_normalize(images_u8.data_ptr(), index.data_ptr() + 8 * s, out[s:].data_ptr(), n, C, H, W,
+                                         float(mean), float(std), _stream()), "vg_u8_gather_normalize")
+    return out
+
+
+def minmax(x):
+    """Device tensor [min(x), max(x)] (no host sync)."""
+    lib = _lib.load()
+    _req(x, "x")
+    n = x.numel()
+    nbytes = lib.vg_minmax_workspace_bytes(n)
+    ws = workspace(nbytes, x.device)
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    check(lib.vg_minmax(x.data_ptr(), n, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "vg_minmax")
+    return out
+
+
+def image_grid_u8(x, nrow=8, padding=2, normalize=False, pad_value=0.0):
+    """torchvision 0.2.1 make_grid + save_image quantisation on the device: x [B,C,H,W] (C = 1 or 3)
+    -> uint8 [GH,GW,3]."""
+    import ctypes
+    lib = _lib.load()
+    _req(x, "x")
+    if x.dim() == 3:
+        x = x.unsqueeze(0)
+    B, C, H, W = x.shape
+    gh, gw = ctypes.c_int(), ctypes.c_int()
+    check(lib.vg_image_grid_shape(B, H, W, nrow, padding, ctypes.byref(gh), ctypes.byref(gw)), "vg_image_grid_shape")
+    mm = minmax(x) if normalize else None
+    grid = torch.empty((gh.value, gw.value, 3), dtype=torch.uint8, device=x.device)
+    check(lib.vg_image_grid_u8(x.data_ptr(), _ptr(mm), grid.data_ptr(), B, C, H, W, nrow, padding, float(pad_value),
+                               _stream()), "vg_image_grid_u8")
+    return grid

@@ -24,6 +24,7 @@
 #define VAEGAN_HIP_H
 
 #include <stddef.h>
+#include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -156,6 +157,28 @@ size_t vg_sqdiff_workspace_bytes(size_t n);
  * divisor = B locally; the global batch under data parallelism. */
 int vg_bce_loss(const float* p, float target, float* loss, float* gp, int B, float divisor,
                 float gscale, void* stream);
+
+/* ---- image I/O either side of the step -----------------
+ * Input pipeline of dataloader/dataset.py:37-43 (ToTensor + Normalize(mean, std) of a
+ * shuffled batch) on a uint8 image cache resident in HBM, layout [N][H][W][C] as decoded:
+ *   out[b][c][h][w] = (cache[index[b]][h][w][c] / 255 - mean) / std      (IEEE fp32, bit-exact)
+ * index holds B int64 image numbers (DEVICE memory), all in [0, N). */
+int vg_u8_gather_normalize(const uint8_t* cache, const int64_t* index, float* out, int B, int C,
+                           int H, int W, float mean, float stdv, void* stream);
+
+/* out2[0] = min(x), out2[1] = max(x) over n floats (DEVICE scalars; exact in any order). */
+size_t vg_minmax_workspace_bytes(size_t n);
+int vg_minmax(const float* x, size_t n, float* out2, void* workspace, size_t workspace_bytes,
+              void* stream);
+
+/* torchvision.utils.save_image / make_grid (pinned 0.2.1) as called by utils/utils.py:12-36:
+ * x[B,C,H,W] (C = 1 or 3) -> uint8 HWC grid[GH][GW][3].  minmax (DEVICE, from vg_minmax; NULL =
+ * normalize=False): v = (clamp(x, min, max) - min) / (max - min + 1e-5); byte = trunc(clamp(
+ * v * 255, 0, 255)).  B == 1 gives the un-padded image; otherwise nrow images per row, `padding`
+ * pixels of pad_value between and around them.  vg_image_grid_shape returns GH, GW. */
+int vg_image_grid_shape(int B, int H, int W, int nrow, int padding, int* grid_h, int* grid_w);
+int vg_image_grid_u8(const float* x, const float* minmax, uint8_t* grid, int B, int C, int H, int W,
+                     int nrow, int padding, float pad_value, void* stream);
 
 #ifdef __cplusplus
 }
