@@ -124,7 +124,8 @@ class DeviceImageDataset:
 
     @classmethod
     def from_files(cls, img_file, lab_file=None, **kw):
-        images = torch.from_numpy(np.load(img_file, mmap_mode="c")   # copy-on-write view: never written, keeps torch quiet)
+        # copy-on-write mapping: never written, but writable as far as torch.from_numpy is concerned
+        images = torch.from_numpy(np.load(img_file, mmap_mode="c"))
         labels = np.load(lab_file) if lab_file else None
         return cls(images, labels, **kw)
 

@@ -47,7 +47,7 @@ def load_resized_u8(path, size):
 
 def to_tensor_normalize(u8_hwc, mean=0.5, std=0.5):
     """ToTensor (float().div(255), HWC -> CHW) then Normalize: t.sub_(mean).div_(std)."""
-    t = torch.from_numpy(np.ascontiguousarray(u8_hwc)).permute(2, 0, 1).contiguous().float().div(255)
+    t = torch.from_numpy(np.array(u8_hwc, dtype=np.uint8, copy=True)).permute(2, 0, 1).contiguous().float().div(255)
     return t.sub_(mean).div_(std)
 
 
