@@ -161,8 +161,17 @@ def _enc_trunk(cin, width):
     return nn.Sequential(*layers)
 
 
-def _enc_head(width, n_hidden):
-    return nn.Sequential(HipLinear(width * 4 * 8 * 8, 2048), HipBatchNorm1d(2048, ops.ACT_RELU),
+def _latent_hw(opt):
+    """Spatial size of the encoder's last feature map = opt.n_z[1:], (8, 8) for 64x64 inputs.  The
+    reference hard-codes 8*8 (model.py:461) and the 16/32/64 output sizes (:558-564); deriving both
+    from opt.n_z reproduces it exactly at n_z = [256, 8, 8] and gives the 128x128 / 256x256
+    variants of BASELINE configs 4-5 (image side = 8 * n_z[1]) without new kernels."""
+    n_z = getattr(opt, "n_z", None)
+    return (8, 8) if n_z is None else (int(n_z[1]), int(n_z[2]))
+
+
+def _enc_head(width, n_hidden, spatial=(8, 8)):
+    return nn.Sequential(HipLinear(width * 4 * spatial[0] * spatial[1], 2048), HipBatchNorm1d(2048, ops.ACT_RELU),
                          FusedIntoBN("ReLU"), HipLinear(2048, n_hidden))
 
 
@@ -187,10 +196,11 @@ class _DecoderMixin:
     def _decode(self, code, n_z):
         bs = code.size(0)
         h = self.preprocess(code).view(-1, n_z[0], n_z[1], n_z[2])
-        h = self.act1(self.deconv1(h, output_size=(bs, 256, 16, 16)))
-        h = self.act2(self.deconv2(h, output_size=(bs, 128, 32, 32)))
-        h = self.act3(self.deconv3(h, output_size=(bs, 32, 64, 64)))
-        return self.activation(self.deconv4(h, output_size=(bs, 3, 64, 64)))
+        zh, zw = n_z[1], n_z[2]          # (8, 8) in the reference: the literals of model.py:558-564
+        h = self.act1(self.deconv1(h, output_size=(bs, 256, 2 * zh, 2 * zw)))
+        h = self.act2(self.deconv2(h, output_size=(bs, 128, 4 * zh, 4 * zw)))
+        h = self.act3(self.deconv3(h, output_size=(bs, 32, 8 * zh, 8 * zw)))
+        return self.activation(self.deconv4(h, output_size=(bs, 3, 8 * zh, 8 * zw)))
 
 
 # -------------------------------------------------------------------- the zoo
@@ -202,8 +212,8 @@ class Encoder_celeba(nn.Module):
         self.input_channels = opt.input_channels
         self.n_hidden = opt.n_hidden
         self.features = _enc_trunk(self.input_channels, representation_size)
-        self.x_to_mu = _enc_head(representation_size, self.n_hidden)
-        self.x_to_logvar = _enc_head(representation_size, self.n_hidden)
+        self.x_to_mu = _enc_head(representation_size, self.n_hidden, _latent_hw(opt))
+        self.x_to_logvar = _enc_head(representation_size, self.n_hidden, _latent_hw(opt))
 
     def reparameterize(self, x, eps=None):
         mu = self.x_to_mu(x)
@@ -262,8 +272,8 @@ class VAE(nn.Module, _DecoderMixin):
         self.input_channels = opt.input_channels
         self.n_hidden = opt.n_hidden
         self.features = _enc_trunk(self.input_channels, representation_size)
-        self.x_to_mu = _enc_head(representation_size, self.n_hidden)
-        self.x_to_logvar = _enc_head(representation_size, self.n_hidden)
+        self.x_to_mu = _enc_head(representation_size, self.n_hidden, _latent_hw(opt))
+        self.x_to_logvar = _enc_head(representation_size, self.n_hidden, _latent_hw(opt))
         self.input_size = opt.n_hidden
         self.representation_size2 = opt.n_z
         self._build_decoder(self.input_size, self.representation_size2)
