@@ -213,20 +213,27 @@ __global__ __launch_bounds__(C::NT, 2) void conv5x5_wgrad_kernel(WArgs A) {
   }
 }
 
-// dw[i] = sum_k ws[k][i] in a fixed order.  A workgroup owns 64 consecutive elements; its 4
-// wavefronts each sum every 4th slab (coalesced 256-B rows), then combine through LDS in
-// wavefront order -- deterministic, and parallel over the slabs when there are many of them.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
-                                                           int n, int splits) {
-  __shared__ float red[4][64];
+// dw[i] = sum_k ws[k][i] in a fixed order.  A workgroup owns 64 consecutive elements; its NW
+// wavefronts each sum every NW-th slab (coalesced 256-B rows), then combine through LDS in a
+// fixed tree -- deterministic.  NW = 4 for the big filters (many workgroups, few slabs each), 16
+// where a small filter was split hundreds of ways (few workgroups: the slab chain is the latency).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                              int n, int splits) {
+  __shared__ float red[NW][64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
   float s = 0.f;
   if (i < n)
-    for (int k = wid; k < splits; k += 4) s += ws[(size_t)k * n + i];
+    for (int k = wid; k < splits; k += NW) s += ws[(size_t)k * n + i];
   red[wid][lane] = s;
   __syncthreads();
-  if (wid == 0 && i < n) dw[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+#pragma unroll
+  for (int w = NW / 2; w >= 2; w >>= 1) {     // pairwise tree over the wavefront partials
+    if (wid < w) red[wid][lane] += red[wid + w][lane];
+    __syncthreads();
+  }
+  if (wid == 0 && i < n) dw[i] = red[0][lane] + red[1][lane];
 }
 
 struct Plan {
@@ -324,8 +331,12 @@ extern "C" int vg_conv5x5_wgrad(const float* x, const float* gy, float* dw, int 
   int rc = (stride == 2) ? dispatch_tw<2>(A, p.tw, p.tm, p.cit, st) : dispatch_tw<1>(A, p.tw, p.tm, p.cit, st);
   if (rc) return rc;
   const int n = Cout * Cin * 25;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, (const float*)workspace, dw, n,
-                     p.splits);
+  if (p.splits >= 64 && cdiv(n, 64) < 1024)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(cdiv(n, 64)), dim3(1024), 0, st, (const float*)workspace, dw, n,
+                       p.splits);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(cdiv(n, 64)), dim3(256), 0, st, (const float*)workspace, dw, n,
+                       p.splits);
   VG_CHECK_LAUNCH();
   return 0;
 }

@@ -6,6 +6,7 @@ lib = _lib.load()
 B = 128
 L = [("dis.c3", 32, 128, 64, 2), ("dis.c6", 128, 256, 32, 2), ("dis.c9", 256, 256, 16, 2), ("enc.f3", 64, 128, 32, 2),
      ("enc.f6", 128, 256, 16, 2), ("dis.c0", 3, 32, 64, 1), ("enc.f0", 3, 64, 64, 2)]
+TARGETS = [int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else (-1, 1024, 2048)
 def timeit(fn, n=10):
     for _ in range(2): fn()
     torch.cuda.synchronize()
@@ -21,7 +22,7 @@ for name, cin, cout, h, s in L:
     res = []
     ref = None
     for ks in (5, 10):
-        for tgt in (-1, 1024, 2048):
+        for tgt in TARGETS:
             lib.vg_debug_set_wgrad(3, ks); lib.vg_debug_set_wgrad(1, tgt)
             out = ops.conv5x5_wgrad(x, gy, s)
             if ref is None:
