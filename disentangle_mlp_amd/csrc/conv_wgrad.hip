@@ -37,6 +37,7 @@ struct WCfg {
   static constexpr int AS = KC + 1;
   static constexpr int STAGE = TM * AS + NPATCH;
   static constexpr int NQP = cdiv(NPATCH, NT), NQA = TM / (NT / 64);
+  static_assert(NQA % 4 == 0 || NQA == 2, "gy rows per thread: whole 16-byte groups");
   static_assert(KS == 1 || STAGE >= 4 * (128 / 32 / (4 / WM)) * 16 * 64, "LDS holds one fragment row of partials per wave");
 };
 
@@ -46,6 +47,7 @@ struct WArgs {
   float* ws;
   int B, Cin, H, W, Cout, OH, OW;
   int mtiles, ntiles, splits, tiles_w, tiles_hw, chunks, chunks_per_split;
+  int vec4;   // gy rows can be read as aligned 16-byte pieces (OW % 4 == 0, 16-byte aligned base)
 };
 
 template <class C>
@@ -99,13 +101,28 @@ __global__ __launch_bounds__(C::NT, 2) void conv5x5_wgrad_kernel(WArgs A) {
       const bool ok = pk[q] >= 0 && ih >= 0 && ih < H && iw >= 0 && iw < W;
       preg[q] = ok ? xb[pk[q] + shift] : 0.f;
     }
-    const int oh = th0 + a_ph, ow = tw0 + a_pw;
-    const bool pok = oh < OH && ow < OW;
-    const float* gb = A.gy + ((size_t)b * Cout + m0 + wid) * OHW + oh * OW + ow;
+    if (A.vec4) {
+      // OW % 4 == 0: 16-byte loads, 16 lanes per 64-pixel row, 4 rows per wavefront instruction
+      const int pix = (lane & 15) * 4, rsub = wid * 4 + (lane >> 4);
+      const int oh = th0 + pix / TW, ow = tw0 + pix % TW;
+      const bool pok = oh < OH && ow < OW;
+      const float* gb = A.gy + ((size_t)b * Cout + m0 + rsub) * OHW + oh * OW + ow;
 #pragma unroll
-    for (int q = 0; q < NQA; ++q) {
-      const bool ok = pok && (m0 + wid + NWV * q) < Cout;
-      areg[q] = ok ? gb[(size_t)q * NWV * OHW] : 0.f;
+      for (int q = 0; q < NQA / 4; ++q) {
+        const bool ok = pok && (m0 + rsub + NWV * 4 * q) < Cout;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4*>(gb + (size_t)q * NWV * 4 * OHW);
+        areg[4 * q] = v[0]; areg[4 * q + 1] = v[1]; areg[4 * q + 2] = v[2]; areg[4 * q + 3] = v[3];
+      }
+    } else {
+      const int oh = th0 + a_ph, ow = tw0 + a_pw;
+      const bool pok = oh < OH && ow < OW;
+      const float* gb = A.gy + ((size_t)b * Cout + m0 + wid) * OHW + oh * OW + ow;
+#pragma unroll
+      for (int q = 0; q < NQA; ++q) {
+        const bool ok = pok && (m0 + wid + NWV * q) < Cout;
+        areg[q] = ok ? gb[(size_t)q * NWV * OHW] : 0.f;
+      }
     }
   };
   auto store_chunk = [&]() {
@@ -114,8 +131,16 @@ __global__ __launch_bounds__(C::NT, 2) void conv5x5_wgrad_kernel(WArgs A) {
       const int e = tid + q * NT;
       if (e < NPATCH) pl[e] = preg[q];
     }
+    if (A.vec4) {
+      const int pix = (lane & 15) * 4, rsub = wid * 4 + (lane >> 4);
 #pragma unroll
-    for (int q = 0; q < NQA; ++q) gyl[(wid + NWV * q) * AS + a_pix] = areg[q];
+      for (int q = 0; q < NQA / 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gyl[(rsub + NWV * 4 * q) * AS + pix + j] = areg[4 * q + j];
+    } else {
+#pragma unroll
+      for (int q = 0; q < NQA; ++q) gyl[(wid + NWV * q) * AS + a_pix] = areg[q];
+    }
   };
 
   // ---- per-lane operand bases
@@ -242,6 +267,7 @@ struct Plan {
 
 int g_wgrad_ks = 2;                 // 8-wave K-split kernel for the 128-row tile (1 = 4-wave form, diagnostics)
 int g_wgrad_cit = 5;                // 10 = 250-column tile for the 128-row tile (measured slower: diagnostics)
+int g_wgrad_vec4 = 1;               // diagnostics: 0 = scalar gy loads everywhere
 int g_wgrad_tm_override = -1;       // diagnostics only (vg_debug_set_conv_tile mode 2)
 int g_wgrad_blocks_target = -1;     // diagnostics only
 
@@ -305,6 +331,7 @@ extern "C" int vg_debug_set_wgrad(int what, int value) {
   else if (what == 1) g_wgrad_blocks_target = value;
   else if (what == 2) g_wgrad_ks = value;
   else if (what == 3) g_wgrad_cit = value;
+  else if (what == 4) g_wgrad_vec4 = value;
   else return VG_ERR_BAD_ARG;
   return 0;
 }
@@ -328,6 +355,7 @@ extern "C" int vg_conv5x5_wgrad(const float* x, const float* gy, float* dw, int 
   A.B = B; A.Cin = Cin; A.H = H; A.W = W; A.Cout = Cout; A.OH = p.OH; A.OW = p.OW;
   A.mtiles = p.mtiles; A.ntiles = p.ntiles; A.splits = p.splits;
   A.tiles_w = p.tiles_w; A.tiles_hw = p.tiles_hw; A.chunks = p.chunks; A.chunks_per_split = p.cps;
+  A.vec4 = (p.OW % 4 == 0 && ((uintptr_t)gy & 15) == 0 && g_wgrad_vec4) ? 1 : 0;
   int rc = (stride == 2) ? dispatch_tw<2>(A, p.tw, p.tm, p.cit, st) : dispatch_tw<1>(A, p.tw, p.tm, p.cit, st);
   if (rc) return rc;
   const int n = Cout * Cin * 25;

@@ -101,6 +101,7 @@ USE_PACKED_FILTERS = True
 _pack_scope_depth = 0
 _pack_cache = {}      # (data_ptr, transposed, stride, shape) -> [valid, version, packed tensor]
 _pack_scratch = {}    # (device, stream, numel) -> tensor, for un-cached packs
+_PACK_CACHE_MAX = 64  # entries (a beta-VAE-GAN iteration uses 21); beyond it the cache is rebuilt
 
 
 class packed_filter_scope:
@@ -110,6 +111,8 @@ class packed_filter_scope:
     def __enter__(self):
         global _pack_scope_depth
         if _pack_scope_depth == 0:
+            if len(_pack_cache) > _PACK_CACHE_MAX:     # weights of trainers that no longer exist
+                _pack_cache.clear()
             invalidate_packed_filters()
         _pack_scope_depth += 1
         return self

@@ -45,7 +45,8 @@ int vg_version(void);
  * never used by the product path. */
 int vg_debug_set_conv_tile(int mode, int variant);
 /* Diagnostics / tuning only: what=0 caps the wgrad cout tile (32/64/128, -1 = heuristic);
- * what=1 sets the split-K workgroup target (default 1024). */
+ * what=1 sets the split-K workgroup target (-1 = heuristic); what=2 the K groups of the 128-row
+ * tile (1 or 2); what=3 the input channels per column tile (5 or 10); what=4: 0 = scalar gy loads. */
 int vg_debug_set_wgrad(int what, int value);
 
 /* ---- 5x5 convolutions, padding 2, stride 1 or 2 ----------------------------

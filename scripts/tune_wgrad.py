@@ -21,14 +21,14 @@ for name, cin, cout, h, s in L:
     gf = 2.0 * B * (h // s) ** 2 * cin * cout * 25 / 1e9
     res = []
     ref = None
-    for ks in (5, 10):
+    for ks in (5, 4):           # 5: default; 4: same with scalar gy loads (vg_debug_set_wgrad(4, 0))
         for tgt in TARGETS:
-            lib.vg_debug_set_wgrad(3, ks); lib.vg_debug_set_wgrad(1, tgt)
+            lib.vg_debug_set_wgrad(4, 1 if ks == 5 else 0); lib.vg_debug_set_wgrad(1, tgt)
             out = ops.conv5x5_wgrad(x, gy, s)
             if ref is None:
                 ref = out.clone()
             err = float((out - ref).abs().max() / ref.abs().max())
             ms = timeit(lambda: ops.conv5x5_wgrad(x, gy, s))
-            res.append(f"cit{ks}/b{tgt}:{ms*1e3:5.0f}us {gf/ms:5.1f}TF e{err:.0e}")
-    lib.vg_debug_set_wgrad(3, 5); lib.vg_debug_set_wgrad(1, -1)
+            res.append(f"{'vec4' if ks == 5 else 'scal'}/b{tgt}:{ms*1e3:5.0f}us {gf/ms:5.1f}TF e{err:.0e}")
+    lib.vg_debug_set_wgrad(4, 1); lib.vg_debug_set_wgrad(1, -1)
     print(f"{name:7s} {gf:5.1f}GF " + " ".join(res), flush=True)
