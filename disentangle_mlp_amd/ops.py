@@ -98,6 +98,10 @@ def reserve_workspace(nbytes, device):
 # (a few microseconds); inside one -- the trainer opens it around an iteration, where it
 # alone decides when weights change -- a pack is reused until `invalidate_packed_filters()`.
 USE_PACKED_FILTERS = True
+# Arithmetic of the forward convolution kernels: "fp32" (exact fp32 MFMA, the product default) or
+# "bf16x3" (OPT-IN: hi/lo-split operands on the bf16 MFMA, ~4e-6 relative error; layers whose
+# input channels are not a multiple of 16 stay on the fp32 kernel).  DESIGN.md section 8.
+CONV_FWD_ARITH = "fp32"
 _pack_scope_depth = 0
 _pack_cache = {}      # (data_ptr, transposed, stride, shape) -> [valid, version, packed tensor]
 _pack_scratch = {}    # (device, stream, numel) -> tensor, for un-cached packs
@@ -138,7 +142,8 @@ def invalidate_packed_filters(params=None):
 
 
 def _packed_filter(lib, w, cout, cin, transposed, stride):
-    n = lib.vg_conv5x5_packed_floats(cout, cin)
+    bf16x3 = transposed == 2                      # hi/lo-split pack of the opt-in forward mode
+    n = lib.vg_conv5x5_packed_bf16x3_bytes(cout, cin) // 4 if bf16x3 else lib.vg_conv5x5_packed_floats(cout, cin)
     if _pack_scope_depth > 0:
         key = (w.data_ptr(), transposed, stride, tuple(w.shape))
         ent = _pack_cache.get(key)
@@ -153,8 +158,11 @@ def _packed_filter(lib, w, cout, cin, transposed, stride):
         buf = _pack_scratch.get(skey)
         if buf is None:
             buf = _pack_scratch[skey] = torch.empty(n, dtype=torch.float32, device=w.device)
-    check(lib.vg_conv5x5_pack(w.data_ptr(), buf.data_ptr(), cout, cin, transposed, stride, _stream()),
-          "vg_conv5x5_pack")
+    if bf16x3:
+        check(lib.vg_conv5x5_pack_bf16x3(w.data_ptr(), buf.data_ptr(), cout, cin, _stream()), "vg_conv5x5_pack_bf16x3")
+    else:
+        check(lib.vg_conv5x5_pack(w.data_ptr(), buf.data_ptr(), cout, cin, transposed, stride, _stream()),
+              "vg_conv5x5_pack")
     if ent is not None:
         ent[0], ent[1] = True, w._version
     return buf
@@ -171,6 +179,12 @@ def conv5x5_fwd(x, w, bias, stride):
         _req(bias, "bias")
     OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
     y = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
+    if CONV_FWD_ARITH == "bf16x3" and Cin % 16 == 0:
+        pk = _packed_filter(lib, w, Cout, Cin, 2, 1)
+        with _timed(("conv_fwd", B, Cin, H, W, Cout, stride)):
+            check(lib.vg_conv5x5_fwd_bf16x3(x.data_ptr(), pk.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W,
+                                            Cout, stride, _stream()), "vg_conv5x5_fwd_bf16x3")
+        return y
     if USE_PACKED_FILTERS:
         pk = _packed_filter(lib, w, Cout, Cin, 0, stride)
         with _timed(("conv_fwd", B, Cin, H, W, Cout, stride)):

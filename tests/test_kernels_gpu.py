@@ -409,3 +409,38 @@ def test_packed_filter_bad_args(H):
     assert lib.vg_conv5x5_pack(w.data_ptr(), pk.data_ptr() + 4, 8, 4, 0, 1, 0) == -1   # misaligned
     assert lib.vg_conv5x5_pack(w.data_ptr(), pk.data_ptr(), 8, 4, 0, 3, 0) == -1       # stride
     assert lib.vg_conv5x5_pack(0, pk.data_ptr(), 8, 4, 0, 1, 0) == -1
+
+
+# ------------------------------------------------------------------ opt-in bf16x3 forward mode
+@pytest.mark.parametrize("B,Cin,Cout,Hs,Ws,stride", [
+    (3, 16, 32, 16, 16, 2), (2, 32, 128, 64, 64, 2), (2, 128, 256, 32, 32, 2), (5, 48, 70, 13, 9, 2),
+    (3, 16, 130, 16, 24, 1), (2, 32, 3, 64, 64, 1), (1, 256, 256, 16, 16, 2), (4, 64, 40, 8, 8, 1)])
+def test_conv_fwd_bf16x3(H, B, Cin, Cout, Hs, Ws, stride):
+    """OPT-IN mode (ops.CONV_FWD_ARITH = "bf16x3"): hi/lo-split operands, hi*hi + hi*lo + lo*hi on the
+    bf16 MFMA, fp32 accumulation.  Stated tolerance: 2e-5 relative L2 against the fp64 oracle (measured
+    ~4e-6; the exact-fp32 default is held to 3e-6)."""
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, Cin, Hs, Ws, generator=g)
+    w = torch.randn(Cout, Cin, 5, 5, generator=g) * 0.05
+    bias = torch.randn(Cout, generator=g)
+    ref = O.conv5x5(x, w, bias, stride)
+    try:
+        H.CONV_FWD_ARITH = "bf16x3"
+        y = H.conv5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), stride)
+        y2 = H.conv5x5_fwd(x.cuda(), w.cuda(), None, stride)
+    finally:
+        H.CONV_FWD_ARITH = "fp32"
+    assert_close(y, ref, 2e-5, "bf16x3 fwd")
+    assert_close(y2, O.conv5x5(x, w, None, stride), 2e-5, "bf16x3 fwd, no bias")
+    e32 = rel_l2(H.conv5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), stride), ref)
+    assert e32 <= 3e-6            # the default path is untouched by the switch
+
+
+def test_conv_fwd_bf16x3_falls_back_when_cin_not_multiple_of_16(H):
+    x, w = _rand(2, 3, 16, 16, seed=1), 0.1 * _rand(8, 3, 5, 5, seed=2)
+    try:
+        H.CONV_FWD_ARITH = "bf16x3"
+        y = H.conv5x5_fwd(x.cuda(), w.cuda(), None, 2)
+    finally:
+        H.CONV_FWD_ARITH = "fp32"
+    assert_close(y, O.conv5x5(x, w, None, 2), 3e-6, "fallback to the fp32 kernel")
