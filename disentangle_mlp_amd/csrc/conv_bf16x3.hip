@@ -1,25 +1,28 @@
-// OPT-IN arithmetic mode of the 5x5 forward convolution (vg_conv5x5_fwd_bf16x3) for gfx950:
-// every fp32 operand is split into two bf16 values (hi = bf16(x), lo = bf16(x - hi)) and each
-// product is evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32
-// accumulation -- 3 bf16 MFMAs per 16 k in 96 cycles where the exact-fp32 MFMA needs 8 x 64.
-// Measured error of a 128 -> 256 stride-2 layer against fp64: ~4e-6 relative (fp32 path: 3.5e-7),
-// so this is NOT the default: the product path stays exact fp32 (conv_igemm.hip); see DESIGN.md
-// section 8 item 1 for the measurements that motivate this kernel.
+// OPT-IN arithmetic mode of the 5x5 convolution / transposed convolution forward kernels
+// (vg_conv5x5_fwd_bf16x3, vg_convT5x5_fwd_bf16x3) for gfx950: every fp32 operand is split into two
+// bf16 values (hi = bf16(x), lo = bf16(x - hi)) and each product is evaluated as
+// lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- 3 bf16 MFMAs per
+// 16 k in 96 cycles where the exact-fp32 MFMA needs 8 x 64.  Measured error against fp64:
+// ~4.5e-6 relative (exact-fp32 path: 5e-7 .. 1e-6), so this is NOT the default: the product path
+// stays exact fp32 (conv_igemm.hip).  DESIGN.md section 8 has the measurements behind it.
 //
-// Same computation as vg_conv5x5_fwd (nn.Conv2d forward, /root/reference/models/model.py:389-398,
-// 450-456, and the data gradient of the transposed convolutions :495-507); requires Cin % 16 == 0.
+// Same computations as vg_conv5x5_fwd / vg_convT5x5_fwd (nn.Conv2d / nn.ConvTranspose2d forward of
+// /root/reference/models/model.py:389-398, 450-456, 495-507 and each other's data gradients);
+// requires Cin % 16 == 0.
 //
-// Structure (one workgroup = 4 wavefronts, 128 output channels x 128 pixels, 2 x 2 fragments of
-// 32 x 32 per wavefront):
+// Structure (one workgroup = 4 wavefronts as WC x WP, FC x FP fragments of 32 x 32 per wavefront):
 //   * K step = 16 input channels of one tap (MFMA k-block 0 / 1 = channels 0-7 / 8-15).
 //   * The input patch of a 16-channel chunk lives in LDS channel-innermost, [plane hi/lo][k-block]
-//     [row][column parity][column] x 8 bf16 (16 B): a lane's B operand is one ds_read_b128 at a
-//     per-lane base + compile-time tap offset; for stride 2 the even / odd columns are kept apart
-//     so that the 32 pixels of a fragment read consecutive 16-byte units.  The fp32 -> hi/lo split
+//     [image][row][column] x 8 bf16 (16 B): a lane's B operand is one ds_read_b128 at a per-lane
+//     base + tap offset.  For the stride-2 forward convolution the even / odd columns of a row are
+//     kept apart so that the 32 pixels of a fragment read consecutive 16-byte units; row strides are
+//     chosen so that the rows a fragment spans fall on disjoint banks.  The fp32 -> hi/lo split
 //     happens once per element, when the prefetched registers are written to LDS.
-//   * The filter never touches LDS: it comes pre-split and pre-packed (vg_conv5x5_pack_bf16x3)
-//     as [chunk*25 + tap][plane][k-block][cout] x 8 bf16, so a lane's A operand is one 16-byte
+//   * The filter never touches LDS: it comes pre-split and pre-packed (vg_conv5x5_pack_bf16x3) as
+//     [parity class][chunk][tap][plane][k-block][cout] x 8 bf16, so a lane's A operand is one 16-byte
 //     global load (32 consecutive cout = 512 contiguous bytes), prefetched one tap ahead.
+//   * The stride-2 transposed convolution runs as its 4 output-parity classes (3x3, 3x2, 2x3, 2x2
+//     taps), exactly as in conv_igemm.hip.
 #include "common.hpp"
 #include "vaegan_hip.h"
 
@@ -27,18 +30,40 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
-constexpr int XNT = 256, XTN = 128;
+enum { X_FWD = 0, X_TR = 1 };
+constexpr int XNT = 256;
 
-template <int S_, int NB_, int TH_, int TW_>
+// 16-byte units per patch row (FWD stride 2: per column parity).  Chosen so that the patch rows a
+// 32-pixel fragment spans start on disjoint groups of 16 units (= 256 B, one LDS bank row):
+// fragments of 2 rows x 16 pixels need the two rows 0 (mod 16) apart, 4 rows x 8 pixels 8 (mod 16).
+constexpr int row_units(int mode, int S, int TW, int PW) {
+  if (mode == X_FWD && S == 2) {                       // returns COLS (per parity); a row is 2 * COLS units
+    const int need = (PW + 1) / 2;
+    if (TW == 8) { int c = need; while ((c & 3) != 2) ++c; return c; }   // 2 rows * 2 * COLS = 8 (mod 16)
+    return (need + 3) & ~3;                                              // 2 rows * 2 * COLS = 0 (mod 16)
+  }
+  if (TW == 16) return (PW + 15) & ~15;
+  if (TW == 8) { int c = PW; while ((c & 15) != 8) ++c; return c; }
+  return (PW + 3) & ~3;
+}
+
+// WC x WP wavefronts (WC * WP = 4), FC x FP fragments each: cout tile 32*WC*FC, pixel tile 32*WP*FP
+template <int MODE_, int S_, int NB_, int TH_, int TW_, int WC_, int FC_, int FP_>
 struct XCfg {
-  static constexpr int S = S_, NB = NB_, TH = TH_, TW = TW_, TM = NB * TH * TW;
-  static constexpr int PH = S * (TH - 1) + 5, PW = S * (TW - 1) + 5;
-  static constexpr int COLS = ((PW + S - 1) / S + 3) & ~3;   // 16-byte units per (row, parity); multiple of 4: rows 2 apart stay bank-disjoint
-  static constexpr int ROWU = S * COLS;                       // units per patch row
-  static constexpr int IMGU = NB * PH * ROWU;                 // units per (plane, k-block) image
-  static constexpr int NUNIT = 2 * NB * PH * PW;              // staged units per chunk (k-block, image, row, real column)
+  static constexpr int MODE = MODE_, S = S_, NB = NB_, TH = TH_, TW = TW_, WC = WC_, WP = 4 / WC_, FC = FC_, FP = FP_;
+  static constexpr int TN = 32 * WC * FC, TM = NB * TH * TW;
+  static constexpr int NTMAX = (MODE == X_FWD) ? 5 : (5 + S - 1) / S;
+  static constexpr int PH = (MODE == X_FWD) ? S * (TH - 1) + 5 : TH + NTMAX - 1;
+  static constexpr int PW = (MODE == X_FWD) ? S * (TW - 1) + 5 : TW + NTMAX - 1;
+  static constexpr bool SPLIT = (MODE == X_FWD && S == 2);       // even / odd columns kept apart
+  static constexpr int COLS = row_units(MODE, S, TW, PW);
+  static constexpr int ROWU = SPLIT ? 2 * COLS : COLS;            // units per patch row
+  static constexpr int IMGU = NB * PH * ROWU;                     // units per (plane, k-block) image
+  static constexpr int NUNIT = 2 * NB * PH * PW;                  // staged units per chunk
   static constexpr int NQ = cdiv(NUNIT, XNT);
-  static_assert(TM == 128, "pixel tile");
+  static constexpr int NCLS = (MODE == X_FWD) ? 1 : S * S;
+  static_assert(TM == 32 * WP * FP, "pixel tile");
+  static_assert(WC == 1 || WC == 2, "wavefront grid");
 };
 
 struct XArgs {
@@ -47,26 +72,41 @@ struct XArgs {
   const float* bias;
   float* y;
   int B, Cin, XH, XW, Cout, CoutP, YH, YW;
-  int ntiles_n, tiles_w, tiles_hw, nblocks;
+  int ntiles_n, tiles_w, tiles_hw, blocks_per_cls;
 };
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-template <class C>
-__global__ __launch_bounds__(XNT, 2) void conv5x5_fwd_bf16x3_kernel(XArgs A) {
-  constexpr int S = C::S, NB = C::NB, TH = C::TH, TW = C::TW, PH = C::PH, PW = C::PW;
-  constexpr int COLS = C::COLS, ROWU = C::ROWU, IMGU = C::IMGU, NQ = C::NQ;
-  __shared__ f32x4 lds[4 * IMGU];     // [plane][k-block][image][row][parity][column]
+// taps of the output-parity classes before (R, SS) (same order as conv_igemm.hip)
+__host__ __device__ constexpr int x_taps_before(int S, int R, int SS) {
+  int n = 0;
+  for (int r = 0; r < S; ++r)
+    for (int s = 0; s < S; ++s) {
+      if (r == R && s == SS) return n;
+      n += ((5 - r + S - 1) / S) * ((5 - s + S - 1) / S);
+    }
+  return n;
+}
+
+template <class C, int R, int SS>
+__device__ __forceinline__ void bf16x3_body(const XArgs& A, f32x4* lds, int bid) {
+  constexpr int MODE = C::MODE, S = C::S, NB = C::NB, TH = C::TH, TW = C::TW, PH = C::PH, PW = C::PW;
+  constexpr int COLS = C::COLS, ROWU = C::ROWU, IMGU = C::IMGU, NQ = C::NQ, FC = C::FC, FP = C::FP;
+  constexpr int NTMAX = C::NTMAX;
+  constexpr int NTH = (MODE == X_FWD) ? 5 : (5 - R + S - 1) / S;   // taps along h / w in this class
+  constexpr int NTW = (MODE == X_FWD) ? 5 : (5 - SS + S - 1) / S;
+  constexpr int NTAP = NTH * NTW;
+  constexpr int PSTEP = (MODE == X_FWD) ? S : 1;                   // patch rows / columns per tile pixel
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int kb = lane >> 5, l32 = lane & 31;
-  const int wc = wid & 1, wp = wid >> 1;
+  const int wc = wid % C::WC, wp = wid / C::WC;
   // XCD-aware placement, as in conv_igemm.hip: the cout tiles of one pixel tile share an XCD
   int nt, pt;
   {
-    const int bid = blockIdx.x, ntn = A.ntiles_n, npatch = A.nblocks / ntn, full = (npatch / 8) * 8 * ntn;
+    const int ntn = A.ntiles_n, npatch = A.blocks_per_cls / ntn, full = (npatch / 8) * 8 * ntn;
     if (bid < full) {
       const int xcd = bid & 7, j = bid >> 3;
       pt = (j / ntn) * 8 + xcd;
@@ -79,9 +119,10 @@ __global__ __launch_bounds__(XNT, 2) void conv5x5_fwd_bf16x3_kernel(XArgs A) {
   }
   const int sp = pt % A.tiles_hw, bg = pt / A.tiles_hw;
   const int th0 = (sp / A.tiles_w) * TH, tw0 = (sp % A.tiles_w) * TW;
-  const int b0 = bg * NB, n0 = nt * XTN;
+  const int b0 = bg * NB, n0 = nt * C::TN;
   const int Cin = A.Cin, Cout = A.Cout, XH = A.XH, XW = A.XW, HW = XH * XW;
-  const int ih0 = th0 * S - 2, iw0 = tw0 * S - 2;
+  const int ih0 = (MODE == X_FWD) ? th0 * S - 2 : th0 - (NTMAX - 1 - 2 / S);
+  const int iw0 = (MODE == X_FWD) ? tw0 * S - 2 : tw0 - (NTMAX - 1 - 2 / S);
   const float* xb = A.x + (size_t)b0 * Cin * HW;
 
   // ---- staging map: unit e = (k-block, image, row, column); addresses clamped, validity masked
@@ -99,7 +140,7 @@ __global__ __launch_bounds__(XNT, 2) void conv5x5_fwd_bf16x3_kernel(XArgs A) {
     const bool ok = (e < C::NUNIT) && ih >= 0 && ih < XH && iw >= 0 && iw < XW && (b0 + nb) < A.B;
     const int nbc = min(nb, A.B - 1 - b0), ihc = min(max(ih, 0), XH - 1), iwc = min(max(iw, 0), XW - 1);
     pofs[q] = (nbc * Cin + kbs * 8) * HW + ihc * XW + iwc;
-    pdst[q] = (e < C::NUNIT) ? kbs * IMGU + (nb * PH + r) * ROWU + (S == 2 ? (col & 1) * COLS + (col >> 1) : col) : -1;
+    pdst[q] = (e < C::NUNIT) ? kbs * IMGU + (nb * PH + r) * ROWU + (C::SPLIT ? (col & 1) * COLS + (col >> 1) : col) : -1;
     pvalid |= ok ? (1u << q) : 0u;
   }
   static_assert(NQ <= 32, "validity mask");
@@ -131,33 +172,35 @@ __global__ __launch_bounds__(XNT, 2) void conv5x5_fwd_bf16x3_kernel(XArgs A) {
   };
 
   // ---- per-lane operand bases
-  int base_b[2];
+  int base_b[FP];
 #pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    const int m = (wp * 2 + f) * 32 + l32;
+  for (int f = 0; f < FP; ++f) {
+    const int m = (wp * FP + f) * 32 + l32;
     const int nb = m / (TH * TW), r = m % (TH * TW);
-    base_b[f] = kb * IMGU + (nb * PH + S * (r / TW)) * ROWU + (r % TW);   // column S*pw: parity 0, index pw
+    // FWD stride 2: column 2*pw has parity 0 and index pw
+    base_b[f] = kb * IMGU + (nb * PH + PSTEP * (r / TW)) * ROWU + (C::SPLIT ? (r % TW) : PSTEP * (r % TW));
   }
   const int CoutP = A.CoutP;
-  const bf16x8* wa[2];
-#pragma unroll
-  for (int g = 0; g < 2; ++g) wa[g] = A.w + (size_t)kb * CoutP + n0 + (wc * 2 + g) * 32 + l32;
   const size_t wstep = (size_t)4 * CoutP;    // units per (chunk, tap) step
+  const int nchunks = Cin / 16;
+  const bf16x8* wa[FC];                      // this class' first step, this lane's cout and k-block
+#pragma unroll
+  for (int g = 0; g < FC; ++g)
+    wa[g] = A.w + (size_t)x_taps_before(S, R, SS) * nchunks * wstep + (size_t)kb * CoutP + n0 + (wc * FC + g) * 32 + l32;
 
-  f32x16 acc[2][2];
+  f32x16 acc[FC][FP];
 #pragma unroll
-  for (int g = 0; g < 2; ++g)
+  for (int g = 0; g < FC; ++g)
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int f = 0; f < FP; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[g][f][r] = 0.f;
 
-  const int nchunks = Cin / 16;
   load_chunk(0);
   store_chunk();
-  bf16x8 a_hi[2][2], a_lo[2][2];     // [buffer][fragment]
+  bf16x8 a_hi[2][FC], a_lo[2][FC];     // [buffer][fragment]
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < FC; ++g) {
     a_hi[0][g] = wa[g][0];
     a_lo[0][g] = wa[g][2 * CoutP];
   }
@@ -166,47 +209,51 @@ __global__ __launch_bounds__(XNT, 2) void conv5x5_fwd_bf16x3_kernel(XArgs A) {
   for (int ch = 0; ch < nchunks; ++ch) {
     const bool more = (ch + 1) < nchunks;
     if (more) load_chunk((ch + 1) * 16);
-    // one filter row (5 taps) per trip of a rolled loop: keeps the filter prefetch one tap deep
-    // (fully unrolled, hipcc hoists all 25 taps' loads and spills); 5 is odd, so the prefetched
-    // step is moved back into buffer 0 at the end of every row and `cur` stays compile-time.
+    // one filter row (NTW taps) per trip of a rolled loop: keeps the filter prefetch one tap deep
+    // (fully unrolled, hipcc hoists every tap's loads and spills).  When NTW is odd the prefetched
+    // step is moved back into buffer 0 at the end of the row, so `cur` stays compile-time.
 #pragma unroll 1
-    for (int kh = 0; kh < 5; ++kh) {
-      const bf16x8* wrow[2] = {wa[0] + ((size_t)ch * 25 + kh * 5) * wstep, wa[1] + ((size_t)ch * 25 + kh * 5) * wstep};
-      const int rowoff = kh * ROWU;
+    for (int ta = 0; ta < NTH; ++ta) {
+      const bf16x8* wrow[FC];
 #pragma unroll
-      for (int kw = 0; kw < 5; ++kw) {
-        const int cur = kw & 1, nxt = cur ^ 1;
+      for (int g = 0; g < FC; ++g) wrow[g] = wa[g] + ((size_t)ch * NTAP + ta * NTW) * wstep;
+      const int rowoff = (MODE == X_FWD) ? ta * ROWU : (NTMAX - 1 - ta) * ROWU;
+#pragma unroll
+      for (int tb = 0; tb < NTW; ++tb) {
+        const int cur = tb & 1, nxt = cur ^ 1;
         // next tap's filter fragments (the pack has one spare step after the last one)
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          a_hi[nxt][g] = wrow[g][(size_t)(kw + 1) * wstep];
-          a_lo[nxt][g] = wrow[g][(size_t)(kw + 1) * wstep + 2 * CoutP];
+        for (int g = 0; g < FC; ++g) {
+          a_hi[nxt][g] = wrow[g][(size_t)(tb + 1) * wstep];
+          a_lo[nxt][g] = wrow[g][(size_t)(tb + 1) * wstep + 2 * CoutP];
         }
-        const int imm = (S == 2 ? (kw & 1) * COLS + (kw >> 1) : kw);
-        bf16x8 b_hi[2], b_lo[2];
+        const int imm = (MODE == X_TR) ? (NTMAX - 1 - tb) : (C::SPLIT ? (tb & 1) * COLS + (tb >> 1) : tb);
+        bf16x8 b_hi[FP], b_lo[FP];
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
+        for (int f = 0; f < FP; ++f) {
           b_hi[f] = __builtin_bit_cast(bf16x8, lds[base_b[f] + rowoff + imm]);
           b_lo[f] = __builtin_bit_cast(bf16x8, lds[base_b[f] + rowoff + imm + 2 * IMGU]);
         }
-        // small terms first, product-major: four independent accumulators between dependent MFMAs
+        // small terms first, product-major: independent accumulators between dependent MFMAs
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < FC; ++g)
 #pragma unroll
-          for (int f = 0; f < 2; ++f) acc[g][f] = mfma_bf16(a_lo[cur][g], b_hi[f], acc[g][f]);
+          for (int f = 0; f < FP; ++f) acc[g][f] = mfma_bf16(a_lo[cur][g], b_hi[f], acc[g][f]);
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < FC; ++g)
 #pragma unroll
-          for (int f = 0; f < 2; ++f) acc[g][f] = mfma_bf16(a_hi[cur][g], b_lo[f], acc[g][f]);
+          for (int f = 0; f < FP; ++f) acc[g][f] = mfma_bf16(a_hi[cur][g], b_lo[f], acc[g][f]);
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < FC; ++g)
 #pragma unroll
-          for (int f = 0; f < 2; ++f) acc[g][f] = mfma_bf16(a_hi[cur][g], b_hi[f], acc[g][f]);
+          for (int f = 0; f < FP; ++f) acc[g][f] = mfma_bf16(a_hi[cur][g], b_hi[f], acc[g][f]);
       }
+      if (NTW & 1) {
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        a_hi[0][g] = a_hi[1][g];
-        a_lo[0][g] = a_lo[1][g];
+        for (int g = 0; g < FC; ++g) {
+          a_hi[0][g] = a_hi[1][g];
+          a_lo[0][g] = a_lo[1][g];
+        }
       }
     }
     __syncthreads();
@@ -219,25 +266,45 @@ __global__ __launch_bounds__(XNT, 2) void conv5x5_fwd_bf16x3_kernel(XArgs A) {
   // ---- epilogue: + bias, NCHW store (as conv_igemm.hip)
   const int YH = A.YH, YW = A.YW;
 #pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    const int m = (wp * 2 + f) * 32 + l32;
+  for (int f = 0; f < FP; ++f) {
+    const int m = (wp * FP + f) * 32 + l32;
     const int nb = m / (TH * TW), r = m % (TH * TW);
-    const int oh = th0 + r / TW, ow = tw0 + r % TW, b = b0 + nb;
+    const int th = th0 + r / TW, tw = tw0 + r % TW, b = b0 + nb;
+    const int oh = (MODE == X_FWD) ? th : S * th + R;
+    const int ow = (MODE == X_FWD) ? tw : S * tw + SS;
     const bool pok = b < A.B && oh < YH && ow < YW;
     float* yb = A.y + ((size_t)b * Cout * YH + oh) * YW + ow;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < FC; ++g) {
       float bv[16];
 #pragma unroll
       for (int r16 = 0; r16 < 16; ++r16) {
-        const int co = min(n0 + (wc * 2 + g) * 32 + acc_row(r16, lane), Cout - 1);
+        const int co = min(n0 + (wc * FC + g) * 32 + acc_row(r16, lane), Cout - 1);
         bv[r16] = A.bias ? A.bias[co] : 0.f;
       }
 #pragma unroll
       for (int r16 = 0; r16 < 16; ++r16) {
-        const int co = n0 + (wc * 2 + g) * 32 + acc_row(r16, lane);
+        const int co = n0 + (wc * FC + g) * 32 + acc_row(r16, lane);
         if (pok && co < Cout) yb[(size_t)co * YH * YW] = acc[g][f][r16] + bv[r16];
       }
+    }
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(XNT, 2) void conv5x5_bf16x3_kernel(XArgs A) {
+  __shared__ f32x4 lds[4 * C::IMGU];     // [plane][k-block][image][row][(parity)][column]
+  int bid = blockIdx.x;
+  if constexpr (C::NCLS == 1) {
+    bf16x3_body<C, 0, 0>(A, lds, bid);
+  } else {
+    const int cls = bid / A.blocks_per_cls;   // class 0 (3x3 taps) first: longest blocks start earliest
+    bid -= cls * A.blocks_per_cls;
+    switch (cls) {
+      case 0: bf16x3_body<C, 0, 0>(A, lds, bid); break;
+      case 1: bf16x3_body<C, 0, 1>(A, lds, bid); break;
+      case 2: bf16x3_body<C, 1, 0>(A, lds, bid); break;
+      default: bf16x3_body<C, 1, 1>(A, lds, bid); break;
     }
   }
 }
@@ -248,41 +315,106 @@ int launch_x(const float* x, const bf16x8* w, const float* bias, float* y, int B
   XArgs A;
   A.x = x; A.w = w; A.bias = bias; A.y = y;
   A.B = B; A.Cin = Cin; A.XH = XH; A.XW = XW; A.Cout = Cout; A.CoutP = (Cout + 127) & ~127;
-  A.YH = (XH - 1) / C::S + 1; A.YW = (XW - 1) / C::S + 1;
-  A.tiles_w = cdiv(A.YW, C::TW);
-  A.tiles_hw = cdiv(A.YH, C::TH) * A.tiles_w;
-  A.ntiles_n = cdiv(Cout, XTN);
-  const long grid = (long)A.ntiles_n * A.tiles_hw * cdiv(B, C::NB);
+  int tsh, tsw;
+  if (C::MODE == X_FWD) {
+    A.YH = (XH - 1) / C::S + 1; A.YW = (XW - 1) / C::S + 1;
+    tsh = A.YH; tsw = A.YW;
+  } else {
+    A.YH = XH * C::S; A.YW = XW * C::S;
+    tsh = XH; tsw = XW;
+  }
+  A.tiles_w = cdiv(tsw, C::TW);
+  A.tiles_hw = cdiv(tsh, C::TH) * A.tiles_w;
+  A.ntiles_n = cdiv(Cout, C::TN);
+  const long per_cls = (long)A.ntiles_n * A.tiles_hw * cdiv(B, C::NB);
+  const long grid = per_cls * C::NCLS;
   if (grid <= 0 || grid > 0x7fffffffL) return VG_ERR_BAD_ARG;
-  A.nblocks = (int)grid;
-  hipLaunchKernelGGL(conv5x5_fwd_bf16x3_kernel<C>, dim3((unsigned)grid), dim3(XNT), 0, st, A);
+  A.blocks_per_cls = (int)per_cls;
+  hipLaunchKernelGGL(conv5x5_bf16x3_kernel<C>, dim3((unsigned)grid), dim3(XNT), 0, st, A);
   VG_CHECK_LAUNCH();
   return 0;
 }
 
-template <int S>
-int dispatch_x(const float* x, const bf16x8* w, const float* bias, float* y, int B, int Cin, int XH, int XW, int Cout,
-               hipStream_t st) {
-  const int tsw = (XW - 1) / S + 1;
-  if (tsw >= 32) return launch_x<XCfg<S, 1, 4, 32>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-  if (tsw >= 16) return launch_x<XCfg<S, 1, 8, 16>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-  return launch_x<XCfg<S, 2, 8, 8>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+int g_x_tile_override = -1;   // diagnostics: 0 = 128 cout x 128 px, 1 = 64 x 128, 2 = 64 x 64, 3 = 32 cout x 128 px
+
+template <int MODE, int S, int WC, int FC, int FP>
+int dispatch_geom(const float* x, const bf16x8* w, const float* bias, float* y, int B, int Cin, int XH, int XW,
+                  int Cout, hipStream_t st) {
+  const int tsw = (MODE == X_FWD) ? (XW - 1) / S + 1 : XW;
+  constexpr int TM = 32 * (4 / WC) * FP;
+  if constexpr (TM == 128) {
+    if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 4, 32, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 8, 16, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    return launch_x<XCfg<MODE, S, 2, 8, 8, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+  } else {
+    if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 2, 32, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 4, 16, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    return launch_x<XCfg<MODE, S, 1, 8, 8, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+  }
 }
 
-// packed[(chunk*25 + tap)][plane][k-block][CoutP] x 8 bf16; one spare (zero) step at the end.
+// Biggest tile that still gives every CU two workgroups (256 CUs): 128 cout x 128 px, else 64 cout x
+// 128 px, else 64 x 64; 32 cout x 128 px (4 wavefronts along the pixels) for thin outputs.
+template <int MODE, int S>
+int dispatch_x(const float* x, const bf16x8* w, const float* bias, float* y, int B, int Cin, int XH, int XW, int Cout,
+               hipStream_t st) {
+  const int tsw = (MODE == X_FWD) ? (XW - 1) / S + 1 : XW, tsh = (MODE == X_FWD) ? (XH - 1) / S + 1 : XH;
+  const int ncls = (MODE == X_TR) ? S * S : 1;
+  const long px128 = (long)cdiv(B * cdiv(tsh, 8) * cdiv(tsw, 8) * 64, 128) * ncls;
+  int var = 2;
+  if (Cout <= 32) var = 3;
+  else if (MODE == X_FWD && Cout > 64 && px128 * cdiv(Cout, 128) >= 512) var = 0;   // transposed: 64 x 128 measured faster
+  else if (px128 * cdiv(Cout, 64) >= 512) var = 1;
+  if (g_x_tile_override >= 0 && g_x_tile_override <= 3) var = g_x_tile_override;
+  if (var == 0) return dispatch_geom<MODE, S, 2, 2, 2>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+  if (var == 1) return dispatch_geom<MODE, S, 2, 1, 2>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+  if (var == 3) return dispatch_geom<MODE, S, 1, 1, 1>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+  return dispatch_geom<MODE, S, 2, 1, 1>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+}
+
+// packed[class][chunk][tap][plane][k-block][CoutP] x 8 bf16 (+ one zero step at the end).
+//   transposed = 0: w is [Cout][Cin][5][5], one class of 25 taps (kh*5 + kw);
+//   transposed = 1: w is [Cin][Cout][5][5], S*S parity classes, tap (a, b) of class (R, SS) is
+//                   (kh, kw) = (R + S*a, SS + S*b).
 __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float* __restrict__ w, bf16x8* __restrict__ p,
-                                                         int Cout, int Cin, int CoutP, int nsteps) {
+                                                         int Cout, int Cin, int CoutP, int nsteps, int transposed,
+                                                         int S) {
   const int co = blockIdx.x * 256 + threadIdx.x;
-  const int s = blockIdx.y;                 // chunk*25 + tap, nsteps = spare
+  const int s = blockIdx.y;                 // step; s == nsteps is the spare
   if (co >= CoutP) return;
-  const int c16 = s / 25, tap = s % 25;
+  const int nchunks = Cin / 16;
+  int c16 = 0, kh = 0, kw = 0;
+  const bool live = s < nsteps && co < Cout;
+  if (s < nsteps) {
+    if (!transposed) {
+      c16 = s / 25;
+      kh = (s % 25) / 5;
+      kw = (s % 25) % 5;
+    } else {
+      int rem = s;
+      for (int R = 0; R < S; ++R)
+        for (int SS = 0; SS < S; ++SS) {
+          const int nth = (5 - R + S - 1) / S, ntw = (5 - SS + S - 1) / S, n = nth * ntw * nchunks;
+          if (rem >= 0 && rem < n) {
+            c16 = rem / (nth * ntw);
+            const int t = rem % (nth * ntw);
+            kh = R + S * (t / ntw);
+            kw = SS + S * (t % ntw);
+            rem = -1;
+          } else if (rem >= 0) {
+            rem -= n;
+          }
+        }
+    }
+  }
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
     bf16x8 hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int ci = c16 * 16 + kb * 8 + j;
-      const float v = (s < nsteps && co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * 25 + tap] : 0.f;
+      float v = 0.f;
+      if (live) v = transposed ? w[((size_t)ci * Cout + co) * 25 + kh * 5 + kw] : w[((size_t)co * Cin + ci) * 25 + kh * 5 + kw];
       const __bf16 h = (__bf16)v;
       hi[j] = h;
       lo[j] = (__bf16)(v - (float)h);
@@ -292,28 +424,48 @@ __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float* __restric
   }
 }
 
+int x_args_ok(const float* x, const void* packed, float* y, int B, int Cin, int H, int W, int Cout, int stride) {
+  if (!x || !packed || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+  return (stride == 1 || stride == 2) && Cin % 16 == 0 && ((uintptr_t)packed & 15) == 0;
+}
+
 }  // namespace
+
+extern "C" int vg_debug_set_conv_bf16x3_tile(int variant) {
+  g_x_tile_override = variant;
+  return 0;
+}
 
 extern "C" size_t vg_conv5x5_packed_bf16x3_bytes(int Cout, int Cin) {
   if (Cout <= 0 || Cin <= 0 || Cin % 16) return 0;
   return (size_t)(Cin / 16 * 25 + 1) * 4 * ((Cout + 127) & ~127) * 16;
 }
 
-extern "C" int vg_conv5x5_pack_bf16x3(const float* w, void* packed, int Cout, int Cin, void* stream) {
+extern "C" int vg_conv5x5_pack_bf16x3(const float* w, void* packed, int Cout, int Cin, int transposed, int stride,
+                                      void* stream) {
   if (!w || !packed || Cout <= 0 || Cin <= 0 || Cin % 16 || ((uintptr_t)packed & 15)) return VG_ERR_BAD_ARG;
+  if (stride != 1 && stride != 2) return VG_ERR_BAD_ARG;
   const int CoutP = (Cout + 127) & ~127, nsteps = Cin / 16 * 25;
   hipLaunchKernelGGL(pack_bf16x3_kernel, dim3(cdiv(CoutP, 256), nsteps + 1), dim3(256), 0, (hipStream_t)stream, w,
-                     (bf16x8*)packed, Cout, Cin, CoutP, nsteps);
+                     (bf16x8*)packed, Cout, Cin, CoutP, nsteps, transposed ? 1 : 0, transposed ? stride : 1);
   VG_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int vg_conv5x5_fwd_bf16x3(const float* x, const void* packed, const float* bias, float* y, int B, int Cin,
                                      int H, int W, int Cout, int stride, void* stream) {
-  if (!x || !packed || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return VG_ERR_BAD_ARG;
-  if ((stride != 1 && stride != 2) || Cin % 16 || ((uintptr_t)packed & 15)) return VG_ERR_BAD_ARG;
+  if (!x_args_ok(x, packed, y, B, Cin, H, W, Cout, stride)) return VG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   const bf16x8* w = (const bf16x8*)packed;
-  if (stride == 2) return dispatch_x<2>(x, w, bias, y, B, Cin, H, W, Cout, st);
-  return dispatch_x<1>(x, w, bias, y, B, Cin, H, W, Cout, st);
+  if (stride == 2) return dispatch_x<X_FWD, 2>(x, w, bias, y, B, Cin, H, W, Cout, st);
+  return dispatch_x<X_FWD, 1>(x, w, bias, y, B, Cin, H, W, Cout, st);
+}
+
+extern "C" int vg_convT5x5_fwd_bf16x3(const float* x, const void* packed, const float* bias, float* y, int B, int Cin,
+                                      int H, int W, int Cout, int stride, void* stream) {
+  if (!x_args_ok(x, packed, y, B, Cin, H, W, Cout, stride)) return VG_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const bf16x8* w = (const bf16x8*)packed;
+  if (stride == 2) return dispatch_x<X_TR, 2>(x, w, bias, y, B, Cin, H, W, Cout, st);
+  return dispatch_x<X_TR, 1>(x, w, bias, y, B, Cin, H, W, Cout, st);
 }

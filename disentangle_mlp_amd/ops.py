@@ -98,10 +98,13 @@ def reserve_workspace(nbytes, device):
 # (a few microseconds); inside one -- the trainer opens it around an iteration, where it
 # alone decides when weights change -- a pack is reused until `invalidate_packed_filters()`.
 USE_PACKED_FILTERS = True
-# Arithmetic of the forward convolution kernels: "fp32" (exact fp32 MFMA, the product default) or
+# Arithmetic of the convolution / transposed-convolution forward kernels (and so of each other's
+# data gradients; the weight gradient is always exact fp32): "fp32" (exact fp32 MFMA, the product default) or
 # "bf16x3" (OPT-IN: hi/lo-split operands on the bf16 MFMA, ~4e-6 relative error; layers whose
 # input channels are not a multiple of 16 stay on the fp32 kernel).  DESIGN.md section 8.
-CONV_FWD_ARITH = "fp32"
+CONV_FWD_ARITH = __import__("os").environ.get("VG_CONV_ARITH", "fp32")
+if CONV_FWD_ARITH not in ("fp32", "bf16x3"):
+    raise ImportError(f"VG_CONV_ARITH={CONV_FWD_ARITH!r}: expected 'fp32' or 'bf16x3'")
 _pack_scope_depth = 0
 _pack_cache = {}      # (data_ptr, transposed, stride, shape) -> [valid, version, packed tensor]
 _pack_scratch = {}    # (device, stream, numel) -> tensor, for un-cached packs
@@ -142,7 +145,7 @@ def invalidate_packed_filters(params=None):
 
 
 def _packed_filter(lib, w, cout, cin, transposed, stride):
-    bf16x3 = transposed == 2                      # hi/lo-split pack of the opt-in forward mode
+    bf16x3 = transposed >= 2                      # 2 / 3: hi/lo-split pack of the opt-in mode (conv / transposed conv)
     n = lib.vg_conv5x5_packed_bf16x3_bytes(cout, cin) // 4 if bf16x3 else lib.vg_conv5x5_packed_floats(cout, cin)
     if _pack_scope_depth > 0:
         key = (w.data_ptr(), transposed, stride, tuple(w.shape))
@@ -159,7 +162,8 @@ def _packed_filter(lib, w, cout, cin, transposed, stride):
         if buf is None:
             buf = _pack_scratch[skey] = torch.empty(n, dtype=torch.float32, device=w.device)
     if bf16x3:
-        check(lib.vg_conv5x5_pack_bf16x3(w.data_ptr(), buf.data_ptr(), cout, cin, _stream()), "vg_conv5x5_pack_bf16x3")
+        check(lib.vg_conv5x5_pack_bf16x3(w.data_ptr(), buf.data_ptr(), cout, cin, transposed - 2, stride, _stream()),
+              "vg_conv5x5_pack_bf16x3")
     else:
         check(lib.vg_conv5x5_pack(w.data_ptr(), buf.data_ptr(), cout, cin, transposed, stride, _stream()),
               "vg_conv5x5_pack")
@@ -209,7 +213,14 @@ def convT5x5_fwd(x, w, bias, stride):
         _req(bias, "bias")
     y = torch.empty((B, Cout, H * stride, W * stride), dtype=torch.float32, device=x.device)
     # stride 1 with <= 4 output channels runs the direct VALU kernel on the plain layout
-    if USE_PACKED_FILTERS and not (stride == 1 and Cout <= 4):
+    thin = stride == 1 and Cout <= 4
+    if CONV_FWD_ARITH == "bf16x3" and Cin % 16 == 0 and not thin:
+        pk = _packed_filter(lib, w, Cout, Cin, 3, stride)
+        with _timed(("convT_fwd", B, Cin, H, W, Cout, stride)):
+            check(lib.vg_convT5x5_fwd_bf16x3(x.data_ptr(), pk.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W,
+                                             Cout, stride, _stream()), "vg_convT5x5_fwd_bf16x3")
+        return y
+    if USE_PACKED_FILTERS and not thin:
         pk = _packed_filter(lib, w, Cout, Cin, 1, stride)
         with _timed(("convT_fwd", B, Cin, H, W, Cout, stride)):
             check(lib.vg_convT5x5_fwd_packed(x.data_ptr(), pk.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W,

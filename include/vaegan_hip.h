@@ -82,15 +82,21 @@ int vg_conv5x5_fwd_packed(const float* x, const float* packed, const float* bias
 int vg_convT5x5_fwd_packed(const float* x, const float* packed, const float* bias, float* y,
                            int B, int Cin, int H, int W, int Cout, int stride, void* stream);
 
-/* OPT-IN arithmetic mode of vg_conv5x5_fwd (not used by default): operands
- * split into bf16 hi/lo pairs, hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation --
- * ~4e-6 relative error against fp64 where the exact-fp32 path has 3.5e-7.  Requires Cin % 16 == 0.
- * `packed` holds vg_conv5x5_packed_bf16x3_bytes(Cout, Cin) bytes (16-byte aligned), written by
- * vg_conv5x5_pack_bf16x3 from w[Cout,Cin,5,5] once per weight version. */
+/* OPT-IN arithmetic mode of vg_conv5x5_fwd / vg_convT5x5_fwd (not used by default; DESIGN.md
+ * section 8): operands split into bf16 hi/lo pairs, lo*hi + hi*lo + hi*hi on the bf16 MFMA with fp32
+ * accumulation -- ~4.5e-6 relative error against fp64 where the exact-fp32 path has 5e-7..1e-6.
+ * Requires Cin % 16 == 0.  `packed` holds vg_conv5x5_packed_bf16x3_bytes(Cout, Cin) bytes (16-byte
+ * aligned), written by vg_conv5x5_pack_bf16x3 once per weight version:
+ *   transposed = 0: from w[Cout,Cin,5,5] for vg_conv5x5_fwd_bf16x3 (stride ignored);
+ *   transposed = 1: from w[Cin,Cout,5,5] for vg_convT5x5_fwd_bf16x3 with the SAME stride. */
+int vg_debug_set_conv_bf16x3_tile(int variant);   /* tuning only: 0 = 128x128, 1 = 64x128, 2 = 64x64, 3 = 32x128, -1 = heuristic */
 size_t vg_conv5x5_packed_bf16x3_bytes(int Cout, int Cin);
-int vg_conv5x5_pack_bf16x3(const float* w, void* packed, int Cout, int Cin, void* stream);
+int vg_conv5x5_pack_bf16x3(const float* w, void* packed, int Cout, int Cin, int transposed, int stride,
+                           void* stream);
 int vg_conv5x5_fwd_bf16x3(const float* x, const void* packed, const float* bias, float* y,
                           int B, int Cin, int H, int W, int Cout, int stride, void* stream);
+int vg_convT5x5_fwd_bf16x3(const float* x, const void* packed, const float* bias, float* y,
+                           int B, int Cin, int H, int W, int Cout, int stride, void* stream);
 
 /* dw[Cout,Cin,5,5] = sum_{b,oh,ow} gy[b,co,oh,ow] * x[b,ci,s*oh+kh-2,s*ow+kw-2].
  * Weight gradient of nn.Conv2d (autograd of model.py:450...; new_betavaegan.py:103,121)

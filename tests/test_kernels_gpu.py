@@ -444,3 +444,42 @@ def test_conv_fwd_bf16x3_falls_back_when_cin_not_multiple_of_16(H):
     finally:
         H.CONV_FWD_ARITH = "fp32"
     assert_close(y, O.conv5x5(x, w, None, 2), 3e-6, "fallback to the fp32 kernel")
+
+
+@pytest.mark.parametrize("B,Cin,Cout,Hs,Ws,stride", [
+    (3, 16, 32, 8, 8, 2), (2, 256, 128, 16, 16, 2), (2, 128, 32, 32, 32, 2), (5, 48, 70, 7, 5, 2),
+    (3, 16, 130, 9, 12, 1), (1, 256, 256, 8, 8, 2), (4, 64, 40, 8, 8, 1), (2, 32, 3, 16, 16, 2)])
+def test_convT_fwd_bf16x3(H, B, Cin, Cout, Hs, Ws, stride):
+    """Transposed convolution (and so the data gradient of the convolutions) in the opt-in bf16x3 mode,
+    every tile variant: 2e-5 relative L2 against the fp64 oracle."""
+    from disentangle_mlp_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(B, Cin, Hs, Ws, generator=g)
+    w = torch.randn(Cin, Cout, 5, 5, generator=g) * 0.05
+    bias = torch.randn(Cout, generator=g)
+    ref = O.convT5x5(x, w, bias, stride)
+    try:
+        H.CONV_FWD_ARITH = "bf16x3"
+        for variant in (-1, 0, 1, 2, 3):
+            lib.vg_debug_set_conv_bf16x3_tile(variant)
+            assert_close(H.convT5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), stride), ref, 2e-5, f"bf16x3 convT tile {variant}")
+    finally:
+        H.CONV_FWD_ARITH = "fp32"
+        lib.vg_debug_set_conv_bf16x3_tile(-1)
+
+
+def test_conv_fwd_bf16x3_every_tile(H):
+    from disentangle_mlp_amd import _lib
+    lib = _lib.load()
+    try:
+        H.CONV_FWD_ARITH = "bf16x3"
+        for (B, Cin, Cout, Hs, Ws, s) in ((3, 16, 70, 16, 24, 2), (5, 32, 33, 8, 8, 1), (2, 16, 140, 40, 72, 2)):
+            x, w = _rand(B, Cin, Hs, Ws, seed=50), 0.1 * _rand(Cout, Cin, 5, 5, seed=51)
+            ref = O.conv5x5(x, w, None, s)
+            for variant in (0, 1, 2, 3):
+                lib.vg_debug_set_conv_bf16x3_tile(variant)
+                assert_close(H.conv5x5_fwd(x.cuda(), w.cuda(), None, s), ref, 2e-5, f"bf16x3 fwd tile {variant}")
+    finally:
+        H.CONV_FWD_ARITH = "fp32"
+        lib.vg_debug_set_conv_bf16x3_tile(-1)
