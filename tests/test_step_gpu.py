@@ -98,8 +98,11 @@ def test_betavaegan_step_vs_golden(T, batch):
     assert int(tr.netEG.state_dict()["act1.0.num_batches_tracked"]) == 3
 
 
-def test_betavaegan_gradients_vs_live_oracle(T):
-    """Per-parameter gradients of all three phases vs the oracle (fp64, host CPU), B=8, with
+@pytest.mark.parametrize("arith,loss_tol,grad_tol", [("fp32", 2e-5, 3e-3), ("bf16x3", 1e-4, 1e-2)])
+def test_betavaegan_gradients_vs_live_oracle(T, arith, loss_tol, grad_tol):
+    """(Also run in the OPT-IN bf16x3 arithmetic of the forward / data-gradient convolutions: 4.5e-6
+    per convolution instead of 5e-7, so losses are held to 1e-4 and gradients to 1e-2 there.)
+    Per-parameter gradients of all three phases vs the oracle (fp64, host CPU), B=8, with
     lr = 0 so that every phase differentiates at the same (initial) weights: this isolates the
     kernels from the chaotic sensitivity of Adam's first sign-like update.  Tolerance 3e-3
     relative L2 per tensor: one LeakyReLU/ReLU unit whose pre-activation rounds to the other
@@ -114,13 +117,18 @@ def test_betavaegan_gradients_vs_live_oracle(T):
     ref_l = osteps.betavaegan_step(eg, d, oeg, od, b["data"], b["noise"], b["eps2"], b["eps3"], beta=25.0,
                                    grad_hook=lambda ph, net: ref_g.__setitem__(
                                        ph, {k: p.grad.detach().clone() for k, p in net.named_parameters()}))
+    from disentangle_mlp_amd import ops
     tr = T.BetaVAEGANTrainer(beta=25.0, lr=0.0)
     got_g = {}
-    out = tr.step(*(b[k].float().cuda() for k in ("data", "noise", "eps2", "eps3")),
-                  grad_hook=lambda ph, net: got_g.__setitem__(
-                      ph, {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}))
+    try:
+        ops.CONV_FWD_ARITH = arith
+        out = tr.step(*(b[k].float().cuda() for k in ("data", "noise", "eps2", "eps3")),
+                      grad_hook=lambda ph, net: got_g.__setitem__(
+                          ph, {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}))
+    finally:
+        ops.CONV_FWD_ARITH = "fp32"
     for k in ("errD_real", "errD_fake", "errG_fake", "errG_recon", "sim", "mse_dec", "kld", "mse_enc"):
-        assert close(float(out[k]), ref_l[k], 2e-5), (k, float(out[k]), ref_l[k])
+        assert close(float(out[k]), ref_l[k], loss_tol), (k, float(out[k]), ref_l[k])
     for ph, key in (("D", "d"), ("EG2", "eg"), ("EG3", "eg")):
         for k, r in ref_g[ph].items():
             if k in BN_SHADOWED[key] and not (k == "x_to_mu.3.bias" and ph == "EG3"):
@@ -128,13 +136,13 @@ def test_betavaegan_gradients_vs_live_oracle(T):
             if float(r.norm()) == 0.0:
                 continue
             e = float((got_g[ph][k].double() - r).norm() / float(r.norm()))
-            assert e <= 3e-3, (ph, k, e)
+            assert e <= grad_tol, (ph, k, e)
     # BatchNorm running statistics after 5 / 2 / 3 forwards: order and count matter
     for net, ref in ((tr.netD, d), (tr.netEG, eg)):
         for (k, v), (_, r) in zip(net.state_dict().items(), ref.state_dict().items()):
             if "running" in k:
                 e = float((v.cpu().double() - r).norm() / max(float(r.norm()), 1e-30))
-                assert e <= 2e-5, (k, e)
+                assert e <= (2e-5 if arith == "fp32" else 1e-4), (k, e)
             if "num_batches" in k:
                 assert int(v) == int(r), k
 
