@@ -3,7 +3,11 @@ reconstruction error must fall.  Also reports host enqueue time per step vs wall
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from disentangle_mlp_amd import ops
 from disentangle_mlp_amd.trainer import BetaVAEGANTrainer
+if len(sys.argv) > 1:
+    ops.CONV_FWD_ARITH = sys.argv[1]          # "fp32" (default) or "bf16x3"
+print("convolution arithmetic:", ops.CONV_FWD_ARITH)
 tr = BetaVAEGANTrainer(beta=25.0)
 g = torch.Generator().manual_seed(7)
 B = 128
