@@ -61,5 +61,6 @@ __device__ __forceinline__ T block_sum(T v, T* red) {
 __host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // cross-file internal entry points (not part of the C ABI)
+int vg_internal_wgrad_reduce(const float* slabs, float* dw, int n, int splits, hipStream_t st);
 int vg_internal_convT_s1_thin(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H,
                               int W, int Cout, hipStream_t st);

@@ -326,6 +326,16 @@ int dispatch_tw(const WArgs& A, int tw, int tm, int cit, hipStream_t st) {
 
 }  // namespace
 
+// shared with wgrad_bf16x3.hip: dw[i] = sum over `splits` slabs of n floats, fixed order
+int vg_internal_wgrad_reduce(const float* slabs, float* dw, int n, int splits, hipStream_t st) {
+  if (splits >= 64 && cdiv(n, 64) < 1024)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(cdiv(n, 64)), dim3(1024), 0, st, slabs, dw, n, splits);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(cdiv(n, 64)), dim3(256), 0, st, slabs, dw, n, splits);
+  VG_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int vg_debug_set_wgrad(int what, int value) {
   if (what == 0) g_wgrad_tm_override = value;
   else if (what == 1) g_wgrad_blocks_target = value;
@@ -358,13 +368,5 @@ extern "C" int vg_conv5x5_wgrad(const float* x, const float* gy, float* dw, int 
   A.vec4 = (p.OW % 4 == 0 && ((uintptr_t)gy & 15) == 0 && g_wgrad_vec4) ? 1 : 0;
   int rc = (stride == 2) ? dispatch_tw<2>(A, p.tw, p.tm, p.cit, st) : dispatch_tw<1>(A, p.tw, p.tm, p.cit, st);
   if (rc) return rc;
-  const int n = Cout * Cin * 25;
-  if (p.splits >= 64 && cdiv(n, 64) < 1024)
-    hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(cdiv(n, 64)), dim3(1024), 0, st, (const float*)workspace, dw, n,
-                       p.splits);
-  else
-    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(cdiv(n, 64)), dim3(256), 0, st, (const float*)workspace, dw, n,
-                       p.splits);
-  VG_CHECK_LAUNCH();
-  return 0;
+  return vg_internal_wgrad_reduce((const float*)workspace, dw, Cout * Cin * 25, p.splits, st);
 }

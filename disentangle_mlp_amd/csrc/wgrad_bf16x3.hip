@@ -1,0 +1,349 @@
+// OPT-IN arithmetic mode of the 5x5 weight gradient (vg_conv5x5_wgrad_bf16x3) for gfx950, the
+// companion of conv_bf16x3.hip: hi/lo-split bf16 operands, lo*hi + hi*lo + hi*hi on
+// v_mfma_f32_32x32x16_bf16, fp32 accumulation (~4.5e-6 relative error; NOT the default).
+//
+//   dw[co][ci][kh][kw] = sum_{b,oh,ow} gy[b][co][oh][ow] * x[b][ci][S*oh+kh-2][S*ow+kw-2]
+//   (autograd of nn.Conv2d / nn.ConvTranspose2d, /root/reference/models/model.py:389-398, 450-456,
+//    495-507; same contract as vg_conv5x5_wgrad)
+//
+// GEMM view: D[co][n = ci*25 + tap], reduction over (image, output pixel).  The bf16 MFMA wants 8
+// consecutive k per lane; "consecutive pixels" would make the patch operand an unaligned 16-byte
+// LDS read, so k runs over IMAGES: one MFMA step = one output pixel x 16 images (k-block 0 / 1 =
+// images 0-7 / 8-15).  Two re-layout passes put both operands batch-innermost, split into hi / lo:
+//   Xp[image group][plane][k-block][ci][h][w]   x 8 images (16 B)   <- x
+//   Gp[image group][pixel][plane][k-block][co]  x 8 images (16 B)   <- gy   (LDS transpose)
+// The kernel (4 wavefronts, 128 co x 5 ci (125 of 128 columns), 2 x 2 fragments per wavefront):
+//   * per chunk = (image group, 4 x 8 output pixels) the x patch [plane][k-block][5 ci][rows][cols]
+//     is copied to LDS as 16-byte units; MFMA column n reads unit (ci, S*oh+kh, S*ow+kw) at a
+//     per-lane base + compile-time pixel offset; row / channel strides are 5 / 9 (mod 16) units so
+//     that column n lands on bank group n mod 16 (conflict-free ds_read_b128);
+//   * the gy operand goes global -> register (32 consecutive co = 512 contiguous bytes), prefetched
+//     one pixel ahead -- no LDS, no barrier for it;
+//   * split-K over chunks, partial slabs summed in a fixed order by conv_wgrad.hip's reduction.
+#include "common.hpp"
+#include "vaegan_hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+constexpr int WNT = 256, WTH = 4, WTW = 8, WCIT = 5, WTM = 128;
+
+template <int S_>
+struct WX {
+  static constexpr int S = S_;
+  static constexpr int PH = S * (WTH - 1) + 5, PW = S * (WTW - 1) + 5;
+  static constexpr int ROWU = PW + ((5 - PW % 16) + 16) % 16;                    // = 5 (mod 16)
+  static constexpr int CIU = PH * ROWU + ((9 - (PH * ROWU) % 16) + 16) % 16;     // = 9 (mod 16)
+  static constexpr int KBU = WCIT * CIU;                                          // units per (plane, k-block)
+  static constexpr int NUNIT = 4 * WCIT * PH * PW;
+  static constexpr int NQ = cdiv(NUNIT, WNT);
+};
+
+struct WXArgs {
+  const bf16x8* xp;
+  const bf16x8* gp;
+  float* ws;
+  int Cin, H, W, Cout, CoP, OH, OW;
+  int mtiles, ntiles, splits, tiles_w, tiles_hw, chunks, chunks_per_split;
+};
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)v[j];
+    hi[j] = h;
+    lo[j] = (__bf16)(v[j] - (float)h);
+  }
+}
+
+// ---- x[B][C][HW] -> Xp[bg][plane][kb][C][HW] x 8 images
+__global__ __launch_bounds__(256) void relayout_x_kernel(const float* __restrict__ x, bf16x8* __restrict__ xp, int B,
+                                                        size_t chw) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int bg = blockIdx.y;
+  if (e >= chw) return;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int b = bg * 16 + kb * 8 + j;
+      v[j] = b < B ? x[(size_t)b * chw + e] : 0.f;
+    }
+    bf16x8 hi, lo;
+    split8(v, hi, lo);
+    xp[((size_t)bg * 4 + kb) * chw + e] = hi;
+    xp[((size_t)bg * 4 + 2 + kb) * chw + e] = lo;
+  }
+}
+
+// ---- gy[B][Co][P] -> Gp[bg][p][plane][kb][CoP] x 8 images; 32 pixels x 32 channels per workgroup
+__global__ __launch_bounds__(256) void relayout_gy_kernel(const float* __restrict__ gy, bf16x8* __restrict__ gp,
+                                                         int B, int Co, int CoP, int P) {
+  __shared__ float tile[8][32][33];
+  const int tid = threadIdx.x;
+  const int p0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int bg = blockIdx.z >> 1, kb = blockIdx.z & 1;
+  {
+    const int r = tid >> 5, pl = tid & 31;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int b = bg * 16 + kb * 8 + j;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int co = co0 + r + 8 * rr;
+        float v = 0.f;
+        if (b < B && co < Co && p0 + pl < P) v = gy[((size_t)b * Co + co) * P + p0 + pl];
+        tile[j][r + 8 * rr][pl] = v;
+      }
+    }
+  }
+  __syncthreads();
+  const int cc = tid & 31;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int pp = (tid >> 5) + 8 * k;
+    if (p0 + pp >= P) continue;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = tile[j][cc][pp];
+    bf16x8 hi, lo;
+    split8(v, hi, lo);
+    const size_t base = (((size_t)bg * P + p0 + pp) * 4 + kb) * CoP + co0 + cc;
+    gp[base] = hi;
+    gp[base + (size_t)2 * CoP] = lo;
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(WNT, 2) void conv5x5_wgrad_bf16x3_kernel(WXArgs A) {
+  constexpr int S = C::S, PH = C::PH, PW = C::PW, ROWU = C::ROWU, CIU = C::CIU, KBU = C::KBU, NQ = C::NQ;
+  __shared__ f32x4 lds[4 * KBU];      // [plane][k-block][ci][row][col] x 8 images
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int kb = lane >> 5, l32 = lane & 31;
+  const int wm = wid & 1, wn = wid >> 1;
+  int bid = blockIdx.x;
+  const int mt = bid % A.mtiles;
+  bid /= A.mtiles;
+  const int nt = bid % A.ntiles, split = bid / A.ntiles;
+  const int m0 = mt * WTM, ci0 = nt * WCIT;
+  const int Cin = A.Cin, Cout = A.Cout, H = A.H, W = A.W, OW = A.OW, CoP = A.CoP;
+  const int HW = H * W, P = A.OH * A.OW;
+
+  // ---- staging map: unit e = (plane*2 + k-block, ci, row, col), one packed descriptor per unit
+  // (row | col << 4 | ci << 9 | pk << 12 | state << 14; state 0 = no unit, 1 = copy, 2 = channel
+  // beyond Cin -> zeros); addresses are rebuilt from it per chunk to keep registers for the tile
+  int desc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int e = tid + q * WNT;
+    const int col = e % PW;
+    int t = e / PW;
+    const int r = t % PH;
+    t /= PH;
+    const int ci = t % WCIT, pk = min(t / WCIT, 3);
+    const int state = e < C::NUNIT ? ((ci0 + ci) < Cin ? 1 : 2) : 0;
+    desc[q] = r | (col << 4) | (ci << 9) | (pk << 12) | (state << 14);
+  }
+  static_assert(PH <= 16 && PW <= 32 && WCIT <= 8, "descriptor fields");
+
+  f32x4 preg[NQ];
+  unsigned pvalid = 0;
+  auto load_chunk = [&](int chunk) {
+    const int bg = chunk / A.tiles_hw, sp = chunk % A.tiles_hw;
+    const int ih0 = S * (sp / A.tiles_w) * WTH - 2, iw0 = S * (sp % A.tiles_w) * WTW - 2;
+    const f32x4* src = reinterpret_cast<const f32x4*>(A.xp) + (size_t)bg * 4 * Cin * HW;
+    pvalid = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int d = desc[q];
+      const int ih = ih0 + (d & 15), iw = iw0 + ((d >> 4) & 31);
+      const int ci = (d >> 9) & 7, pk = (d >> 12) & 3;
+      const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
+      pvalid |= ok ? (1u << q) : 0u;
+      preg[q] = src[(pk * Cin + min(ci0 + ci, Cin - 1)) * HW + min(max(ih, 0), H - 1) * W + min(max(iw, 0), W - 1)];
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int d = desc[q];
+      const int state = d >> 14;
+      const int dst = ((d >> 12) & 3) * KBU + ((d >> 9) & 7) * CIU + (d & 15) * ROWU + ((d >> 4) & 31);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      if (state != 0) lds[dst] = (state == 1 && ((pvalid >> q) & 1u)) ? preg[q] : z;
+    }
+  };
+  static_assert(NQ <= 32, "validity mask");
+
+  // ---- per-lane operand bases
+  int base_b[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int n = min((wn * 2 + f) * 32 + l32, WCIT * 25 - 1);     // columns 125..127: any valid unit (result unused)
+    const int ci = n / 25, tap = n % 25;
+    base_b[f] = kb * KBU + ci * CIU + (tap / 5) * ROWU + tap % 5;
+  }
+  const bf16x8* ga[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) ga[g] = A.gp + (size_t)kb * CoP + m0 + (wm * 2 + g) * 32 + l32;
+  const size_t gstep = (size_t)4 * CoP;     // units per pixel
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[g][f][r] = 0.f;
+
+  const int c_begin = split * A.chunks_per_split;
+  const int c_end = min(c_begin + A.chunks_per_split, A.chunks);
+  if (c_begin < c_end) {
+    for (int ch = c_begin; ch < c_end; ++ch) {
+      // the patch is staged without a register prefetch across the MFMA phase (17 x 16 bytes per thread
+      // would not fit next to the tile); the CU's second workgroup computes while this one copies
+      load_chunk(ch);
+      store_chunk();
+      __syncthreads();
+      const int bg = ch / A.tiles_hw, sp = ch % A.tiles_hw;
+      const int th0 = (sp / A.tiles_w) * WTH, tw0 = (sp % A.tiles_w) * WTW;
+      bf16x8 a_hi[2][2], a_lo[2][2];
+      {
+        const size_t p = (size_t)bg * P + (size_t)th0 * OW + tw0;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          a_hi[0][g] = ga[g][p * gstep];
+          a_lo[0][g] = ga[g][p * gstep + 2 * CoP];
+        }
+      }
+#pragma unroll 1
+      for (int ph = 0; ph < WTH; ++ph) {
+        const size_t prow = (size_t)bg * P + (size_t)(th0 + ph) * OW + tw0;
+        const size_t pnext = (ph + 1 < WTH) ? prow + OW : prow;        // first pixel of the next tile row
+        const int brow = S * ph * ROWU;
+#pragma unroll
+        for (int pw = 0; pw < WTW; ++pw) {
+          const int cur = pw & 1, nxt = cur ^ 1;
+          const size_t pn = (pw + 1 < WTW) ? prow + pw + 1 : pnext;
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            a_hi[nxt][g] = ga[g][pn * gstep];
+            a_lo[nxt][g] = ga[g][pn * gstep + 2 * CoP];
+          }
+          bf16x8 b_hi[2], b_lo[2];
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            b_hi[f] = __builtin_bit_cast(bf16x8, lds[base_b[f] + brow + S * pw]);
+            b_lo[f] = __builtin_bit_cast(bf16x8, lds[base_b[f] + brow + S * pw + 2 * KBU]);
+          }
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) acc[g][f] = mfma_bf16(a_lo[cur][g], b_hi[f], acc[g][f]);
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) acc[g][f] = mfma_bf16(a_hi[cur][g], b_lo[f], acc[g][f]);
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) acc[g][f] = mfma_bf16(a_hi[cur][g], b_hi[f], acc[g][f]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- partial slab: ws[split][co][ci*25 + tap]
+  float* wsb = A.ws + (size_t)split * Cout * Cin * 25;
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int n = (wn * 2 + f) * 32 + l32;
+    const bool nok = n < WCIT * 25 && (ci0 + n / 25) < Cin;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int r16 = 0; r16 < 16; ++r16) {
+        const int co = m0 + (wm * 2 + g) * 32 + acc_row(r16, lane);
+        if (nok && co < Cout) wsb[((size_t)co * Cin + ci0) * 25 + n] = acc[g][f][r16];
+      }
+  }
+}
+
+struct XPlan {
+  int BG, CoP, OH, OW, mtiles, ntiles, tiles_w, tiles_hw, chunks, cps, splits;
+  size_t xp_bytes, gp_bytes, slab_bytes;
+};
+
+bool make_xplan(int B, int Cin, int H, int W, int Cout, int S, XPlan& p) {
+  p.OH = (H - 1) / S + 1;
+  p.OW = (W - 1) / S + 1;
+  if (p.OH % WTH || p.OW % WTW) return false;          // whole 4 x 8 pixel tiles only (caller falls back to fp32)
+  p.BG = cdiv(B, 16);
+  p.CoP = (Cout + 127) & ~127;
+  p.mtiles = cdiv(Cout, WTM);
+  p.ntiles = cdiv(Cin, WCIT);
+  p.tiles_w = p.OW / WTW;
+  p.tiles_hw = p.tiles_w * (p.OH / WTH);
+  p.chunks = p.BG * p.tiles_hw;
+  const int tiles = p.mtiles * p.ntiles;
+  int want = cdiv(tiles >= 32 ? 2048 : 1024, tiles);
+  if (want > p.chunks) want = p.chunks;
+  if (want < 1) want = 1;
+  p.cps = cdiv(p.chunks, want);
+  p.splits = cdiv(p.chunks, p.cps);
+  p.xp_bytes = (size_t)p.BG * 4 * Cin * H * W * 16;
+  p.gp_bytes = (size_t)p.BG * p.OH * p.OW * 4 * p.CoP * 16;
+  p.slab_bytes = (size_t)p.splits * Cout * Cin * 25 * sizeof(float);
+  return true;
+}
+
+}  // namespace
+
+extern "C" size_t vg_conv5x5_wgrad_bf16x3_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return 0;
+  XPlan p;
+  if (!make_xplan(B, Cin, H, W, Cout, stride, p)) return 0;     // 0: shape not supported by this mode
+  return p.xp_bytes + p.gp_bytes + p.slab_bytes;
+}
+
+extern "C" int vg_conv5x5_wgrad_bf16x3(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W,
+                                       int Cout, int stride, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !gy || !dw || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return VG_ERR_BAD_ARG;
+  if (stride != 1 && stride != 2) return VG_ERR_BAD_ARG;
+  XPlan p;
+  if (!make_xplan(B, Cin, H, W, Cout, stride, p)) return VG_ERR_BAD_ARG;
+  if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < p.xp_bytes + p.gp_bytes + p.slab_bytes)
+    return VG_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  bf16x8* xp = (bf16x8*)workspace;
+  bf16x8* gp = (bf16x8*)((char*)workspace + p.xp_bytes);
+  float* slabs = (float*)((char*)workspace + p.xp_bytes + p.gp_bytes);
+  const size_t chw = (size_t)Cin * H * W;
+  const int P = p.OH * p.OW;
+  if (cdiv((long)chw, 256L) > 0x7fffffffL || p.BG > 65535 || p.BG * 2 > 65535 || p.CoP / 32 > 65535) return VG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(relayout_x_kernel, dim3((unsigned)((chw + 255) / 256), p.BG), dim3(256), 0, st, x, xp, B, chw);
+  VG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(relayout_gy_kernel, dim3(cdiv(P, 32), p.CoP / 32, p.BG * 2), dim3(256), 0, st, gy, gp, B, Cout,
+                     p.CoP, P);
+  VG_CHECK_LAUNCH();
+  WXArgs A;
+  A.xp = xp; A.gp = gp; A.ws = slabs;
+  A.Cin = Cin; A.H = H; A.W = W; A.Cout = Cout; A.CoP = p.CoP; A.OH = p.OH; A.OW = p.OW;
+  A.mtiles = p.mtiles; A.ntiles = p.ntiles; A.splits = p.splits; A.tiles_w = p.tiles_w; A.tiles_hw = p.tiles_hw;
+  A.chunks = p.chunks; A.chunks_per_split = p.cps;
+  const long grid = (long)p.mtiles * p.ntiles * p.splits;
+  if (grid > 0x7fffffffL) return VG_ERR_BAD_ARG;
+  if (stride == 2)
+    hipLaunchKernelGGL(conv5x5_wgrad_bf16x3_kernel<WX<2>>, dim3((unsigned)grid), dim3(WNT), 0, st, A);
+  else
+    hipLaunchKernelGGL(conv5x5_wgrad_bf16x3_kernel<WX<1>>, dim3((unsigned)grid), dim3(WNT), 0, st, A);
+  VG_CHECK_LAUNCH();
+  return vg_internal_wgrad_reduce(slabs, dw, Cout * Cin * 25, p.splits, st);
+}

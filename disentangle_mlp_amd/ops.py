@@ -103,6 +103,7 @@ USE_PACKED_FILTERS = True
 # "bf16x3" (OPT-IN: hi/lo-split operands on the bf16 MFMA, ~4e-6 relative error; layers whose
 # input channels are not a multiple of 16 stay on the fp32 kernel).  DESIGN.md section 8.
 CONV_FWD_ARITH = __import__("os").environ.get("VG_CONV_ARITH", "fp32")
+WGRAD_BF16X3 = True      # within the bf16x3 mode: False keeps the weight gradient on the exact-fp32 kernel
 if CONV_FWD_ARITH not in ("fp32", "bf16x3"):
     raise ImportError(f"VG_CONV_ARITH={CONV_FWD_ARITH!r}: expected 'fp32' or 'bf16x3'")
 _pack_scope_depth = 0
@@ -242,6 +243,14 @@ def conv5x5_wgrad(x, gy, stride, out=None):
     if gy.shape != (B, Cout, OH, OW):
         raise RuntimeError(f"conv5x5_wgrad: gy {tuple(gy.shape)} does not match x {tuple(x.shape)} stride {stride}")
     dw = out if out is not None else torch.empty((Cout, Cin, 5, 5), dtype=torch.float32, device=x.device)
+    if CONV_FWD_ARITH == "bf16x3" and WGRAD_BF16X3 and Cin >= 16:     # 3-channel inputs: the re-layout of gy costs more than it saves
+        need = lib.vg_conv5x5_wgrad_bf16x3_workspace_bytes(B, Cin, H, W, Cout, stride)    # 0: shape not taken
+        if need:
+            ws = workspace(need, x.device)
+            with _timed(("conv_wgrad", B, Cin, H, W, Cout, stride)):
+                check(lib.vg_conv5x5_wgrad_bf16x3(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout, stride,
+                                                  ws.data_ptr(), ws.numel(), _stream()), "vg_conv5x5_wgrad_bf16x3")
+            return dw
     need = lib.vg_conv5x5_wgrad_workspace_bytes(B, Cin, H, W, Cout, stride)
     ws = workspace(need, x.device)
     with _timed(("conv_wgrad", B, Cin, H, W, Cout, stride)):

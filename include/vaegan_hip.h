@@ -97,6 +97,13 @@ int vg_conv5x5_fwd_bf16x3(const float* x, const void* packed, const float* bias,
                           int B, int Cin, int H, int W, int Cout, int stride, void* stream);
 int vg_convT5x5_fwd_bf16x3(const float* x, const void* packed, const float* bias, float* y,
                            int B, int Cin, int H, int W, int Cout, int stride, void* stream);
+/* vg_conv5x5_wgrad in the same opt-in arithmetic.  The reduction runs over images in groups of 16
+ * (operands re-laid batch-innermost inside the call; B is zero-padded to a multiple of 16); needs
+ * OH % 4 == 0 and OW % 8 == 0 -- the workspace query returns 0 for shapes it does not take
+ * (use vg_conv5x5_wgrad).  workspace: 16-byte aligned. */
+size_t vg_conv5x5_wgrad_bf16x3_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride);
+int vg_conv5x5_wgrad_bf16x3(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W,
+                            int Cout, int stride, void* workspace, size_t workspace_bytes, void* stream);
 
 /* dw[Cout,Cin,5,5] = sum_{b,oh,ow} gy[b,co,oh,ow] * x[b,ci,s*oh+kh-2,s*ow+kw-2].
  * Weight gradient of nn.Conv2d (autograd of model.py:450...; new_betavaegan.py:103,121)

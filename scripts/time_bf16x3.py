@@ -61,3 +61,22 @@ for name, cin, cout, h in TR:
     ops.CONV_FWD_ARITH = "fp32"
     lib.vg_debug_set_conv_bf16x3_tile(-1)
     print(f"TR {name:9s} {gf:5.1f} GF  " + "   ".join(res), flush=True)
+
+WG = [("dis.c3", 32, 128, 64, 2), ("dis.c6", 128, 256, 32, 2), ("dis.c9", 256, 256, 16, 2), ("enc.f3", 64, 128, 32, 2),
+      ("enc.f6", 128, 256, 16, 2), ("dis.c0", 3, 32, 64, 1), ("enc.f0", 3, 64, 64, 2)]
+for name, cin, cout, h, s in WG:
+    x = torch.randn(B, cin, h, h, device="cuda")
+    gy = torch.randn(B, cout, h // s, h // s, device="cuda")
+    gf = 2.0 * B * (h // s) ** 2 * cin * cout * 25 / 1e9
+    res = []
+    ref = None
+    for mode in ("fp32", "bf16x3"):
+        ops.CONV_FWD_ARITH = mode
+        out = ops.conv5x5_wgrad(x, gy, s)
+        if ref is None:
+            ref = out.double()
+        err = float((out.double() - ref).norm() / ref.norm())
+        ms = timeit(lambda: ops.conv5x5_wgrad(x, gy, s))
+        res.append(f"{mode}: {ms*1e3:5.0f}us {gf/ms:5.1f}TF (vs fp32 kernel {err:.0e})")
+    ops.CONV_FWD_ARITH = "fp32"
+    print(f"WGRAD {name:7s} {gf:5.1f} GF  " + "   ".join(res), flush=True)

@@ -483,3 +483,39 @@ def test_conv_fwd_bf16x3_every_tile(H):
     finally:
         H.CONV_FWD_ARITH = "fp32"
         lib.vg_debug_set_conv_bf16x3_tile(-1)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,Hs,Ws,stride", [
+    (16, 16, 32, 16, 16, 2), (20, 32, 128, 16, 32, 2), (5, 3, 32, 8, 16, 1), (33, 7, 130, 16, 16, 2),
+    (16, 128, 256, 8, 16, 2), (3, 64, 40, 4, 8, 1)])
+def test_conv_wgrad_bf16x3(H, B, Cin, Cout, Hs, Ws, stride):
+    """Weight gradient in the opt-in bf16x3 arithmetic (reduction over images in groups of 16, batch
+    zero-padded): 2e-5 relative L2 against the fp64 oracle; shapes whose output is not made of whole
+    4 x 8 pixel tiles fall back to the exact-fp32 kernel."""
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(B, Cin, Hs, Ws, generator=g)
+    w = torch.randn(Cout, Cin, 5, 5, generator=g) * 0.05
+    OH, OW = (Hs - 1) // stride + 1, (Ws - 1) // stride + 1
+    gy = torch.randn(B, Cout, OH, OW, generator=g)
+    _, gw_ref = O.conv5x5_grads(x, w, gy, stride)
+    try:
+        H.CONV_FWD_ARITH = "bf16x3"
+        gw = H.conv5x5_wgrad(x.cuda(), gy.cuda(), stride)
+    finally:
+        H.CONV_FWD_ARITH = "fp32"
+    assert_close(gw, gw_ref, 2e-5, "bf16x3 wgrad")
+
+
+def test_conv_wgrad_bf16x3_unsupported_shape_falls_back(H):
+    from disentangle_mlp_amd import _lib
+    lib = _lib.load()
+    assert lib.vg_conv5x5_wgrad_bf16x3_workspace_bytes(4, 8, 10, 10, 8, 2) == 0     # 5 x 5 outputs
+    assert lib.vg_conv5x5_wgrad_bf16x3_workspace_bytes(4, 8, 16, 16, 8, 2) > 0
+    x, gy = _rand(2, 3, 10, 10, seed=3), _rand(2, 4, 5, 5, seed=4)
+    w = 0.1 * _rand(4, 3, 5, 5, seed=5)
+    try:
+        H.CONV_FWD_ARITH = "bf16x3"
+        gw = H.conv5x5_wgrad(x.cuda(), gy.cuda(), 2)
+    finally:
+        H.CONV_FWD_ARITH = "fp32"
+    assert_close(gw, O.conv5x5_grads(x, w, gy, 2)[1], 3e-6, "fallback")
