@@ -162,8 +162,8 @@ def main():
             torch.cuda.synchronize()
             e2 = time.perf_counter() - t1
             opt_in = {"value": round(B * args.steps / e2, 2), "unit": "images/s", "ms_per_step": round(e2 / args.steps * 1e3, 3),
-                      "dtype": "bf16x3 (conv fwd / dgrad: hi/lo-split operands, 3 bf16 MFMAs per product, fp32 accumulate) "
-                               "+ fp32 (weight gradient, everything else)",
+                      "dtype": "bf16x3 (conv fwd / dgrad / wgrad: hi/lo-split operands, 3 bf16 MFMAs per product, fp32 "
+                               "accumulate) + fp32 (3-channel layers, everything else)",
                       "conv_rel_error_vs_fp64": 4.5e-6, "default": False,
                       "losses_finite": all(bool(torch.isfinite(v).all()) for v in out2.values()),
                       "note": "ops.CONV_FWD_ARITH / VG_CONV_ARITH=bf16x3; tests hold it to 2e-5 per convolution "
@@ -200,8 +200,8 @@ def main():
             "metric": "celeba64_betavaegan_train_images_per_sec", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp32" if arith == "fp32" else "bf16x3 (conv fwd/dgrad: hi/lo-split operands on the bf16 MFMA, "
-                                                    "fp32 accumulate) + fp32 (weight gradient, everything else)",
+            "dtype": "fp32" if arith == "fp32" else "bf16x3 (convolutions: hi/lo-split operands on the bf16 MFMA, "
+                                                    "fp32 accumulate) + fp32 (3-channel layers, everything else)",
             "data": "synthetic",
             "config": {"workload": "new_betavaegan.py beta=25 VAE-GAN iteration (D + decoder + encoder phases, "
                                    "3 Adam steps), CelebA 64x64, per-GPU batch %d" % B,

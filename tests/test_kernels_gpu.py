@@ -2,6 +2,7 @@
 reference's ATen ops) and the committed golden KATs.  fp32 path, exact-fp32 MFMA:
 tolerance = relative L2 error <= 2e-6 * sqrt(K/64 + 1) style bounds written per test."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -10,6 +11,10 @@ import torch
 from oracle import ops as O
 
 pytestmark = pytest.mark.gpu
+
+# Convolution tolerance (relative L2 against the fp64 oracle): 3e-6 for the default exact-fp32 kernels;
+# 2e-5 when the suite is run with VG_CONV_ARITH=bf16x3 exported (the opt-in split-bf16 arithmetic).
+CONV_TOL = 3e-6 if os.environ.get("VG_CONV_ARITH", "fp32") == "fp32" else 2e-5
 
 
 @pytest.fixture(scope="module")
@@ -125,7 +130,7 @@ def test_conv_layers(H, Cin, Cout, Hs, stride, B):
     x, w, b = _rand(B, Cin, Hs, Hs, seed=1), 0.05 * _rand(Cout, Cin, 5, 5, seed=2), _rand(Cout, seed=3)
     y_ref = O.conv5x5(x, w, b, stride)
     y = H.conv5x5_fwd(x.cuda(), w.cuda(), b.cuda(), stride)
-    tol = 3e-6
+    tol = CONV_TOL
     assert_close(y, y_ref, tol, "conv fwd")
     gy = _rand(*y_ref.shape, seed=4)
     gx_ref, gw_ref = O.conv5x5_grads(x, w, gy, stride)
@@ -141,7 +146,7 @@ def test_convT_layers(H, Cin, Cout, Hs, stride, B):
     x, w, b = _rand(B, Cin, Hs, Hs, seed=5), 0.05 * _rand(Cin, Cout, 5, 5, seed=6), _rand(Cout, seed=7)
     y_ref = O.convT5x5(x, w, b, stride)
     y = H.convT5x5_fwd(x.cuda(), w.cuda(), b.cuda(), stride)
-    tol = 3e-6
+    tol = CONV_TOL
     assert_close(y, y_ref, tol, "convT fwd")
     gy = _rand(*y_ref.shape, seed=8)
     gx_ref, gw_ref = O.convT5x5_grads(x, w, gy, stride)
@@ -159,16 +164,16 @@ def test_conv_ragged(H, B, Cin, Cout, Hs, Ws, stride):
     """Ragged shapes: tiles partly outside the image, channel counts off the tile grid."""
     x, w, b = _rand(B, Cin, Hs, Ws, seed=9), _rand(Cout, Cin, 5, 5, seed=10), _rand(Cout, seed=11)
     y_ref = O.conv5x5(x, w, b, stride)
-    assert_close(H.conv5x5_fwd(x.cuda(), w.cuda(), b.cuda(), stride), y_ref, 3e-6, "fwd")
+    assert_close(H.conv5x5_fwd(x.cuda(), w.cuda(), b.cuda(), stride), y_ref, CONV_TOL, "fwd")
     gy = _rand(*y_ref.shape, seed=12)
     gx_ref, gw_ref = O.conv5x5_grads(x, w, gy, stride)
-    assert_close(H.conv5x5_wgrad(x.cuda(), gy.cuda(), stride), gw_ref, 3e-6, "wgrad")
+    assert_close(H.conv5x5_wgrad(x.cuda(), gy.cuda(), stride), gw_ref, CONV_TOL, "wgrad")
     if Hs % stride == 0 and Ws % stride == 0:
-        assert_close(H.convT5x5_fwd(gy.cuda(), w.cuda(), None, stride), gx_ref, 3e-6, "dgrad")
+        assert_close(H.convT5x5_fwd(gy.cuda(), w.cuda(), None, stride), gx_ref, CONV_TOL, "dgrad")
     # transposed conv with the same tensors: x2 (B,Cout,oh,ow) -> (B,Cin,s*oh,s*ow)
     wt = _rand(Cout, Cin, 5, 5, seed=13)
     yt_ref = O.convT5x5(gy, wt, None, stride)
-    assert_close(H.convT5x5_fwd(gy.cuda(), wt.cuda(), None, stride), yt_ref, 3e-6, "convT fwd")
+    assert_close(H.convT5x5_fwd(gy.cuda(), wt.cuda(), None, stride), yt_ref, CONV_TOL, "convT fwd")
 
 
 @pytest.mark.parametrize("shape,act", [((8, 32, 64, 64), "lrelu"), ((8, 256, 8, 8), "relu"), ((5, 7, 3, 5), "none"),
@@ -232,11 +237,11 @@ def test_every_tile_variant(H, variant):
         for (B, Cin, Cout, Hs, Ws) in ((3, 10, 70, 16, 24), (5, 6, 33, 8, 8), (2, 4, 140, 40, 72)):
             x, w = _rand(B, Cin, Hs, Ws, seed=40), 0.1 * _rand(Cout, Cin, 5, 5, seed=41)
             lib.vg_debug_set_conv_tile(0, variant)
-            assert_close(H.conv5x5_fwd(x.cuda(), w.cuda(), None, 2), O.conv5x5(x, w, None, 2), 3e-6,
+            assert_close(H.conv5x5_fwd(x.cuda(), w.cuda(), None, 2), O.conv5x5(x, w, None, 2), CONV_TOL,
                          f"fwd variant {variant}")
             wt = 0.1 * _rand(Cin, Cout, 5, 5, seed=42)
             lib.vg_debug_set_conv_tile(1, variant)
-            assert_close(H.convT5x5_fwd(x.cuda(), wt.cuda(), None, 2), O.convT5x5(x, wt, None, 2), 3e-6,
+            assert_close(H.convT5x5_fwd(x.cuda(), wt.cuda(), None, 2), O.convT5x5(x, wt, None, 2), CONV_TOL,
                          f"tr variant {variant}")
     finally:
         lib.vg_debug_set_conv_tile(0, -1)
@@ -333,11 +338,11 @@ def test_conv_random_shapes(H):
         w, b = 0.2 * _rand(Cout, Cin, 5, 5, seed=200 + case), _rand(Cout, seed=300 + case)
         tag = f"case {case}: B{B} Cin{Cin} Cout{Cout} {Hs}x{Ws} s{stride}"
         y_ref = O.conv5x5(x, w, b, stride)
-        assert_close(H.conv5x5_fwd(x.cuda(), w.cuda(), b.cuda(), stride), y_ref, 3e-6, tag + " fwd")
+        assert_close(H.conv5x5_fwd(x.cuda(), w.cuda(), b.cuda(), stride), y_ref, CONV_TOL, tag + " fwd")
         gy = _rand(*y_ref.shape, seed=400 + case)
         gx_ref, gw_ref = O.conv5x5_grads(x, w, gy, stride)
-        assert_close(H.convT5x5_fwd(gy.cuda(), w.cuda(), None, stride), gx_ref, 3e-6, tag + " dgrad")
-        assert_close(H.conv5x5_wgrad(x.cuda(), gy.cuda(), stride), gw_ref, 3e-6, tag + " wgrad")
+        assert_close(H.convT5x5_fwd(gy.cuda(), w.cuda(), None, stride), gx_ref, CONV_TOL, tag + " dgrad")
+        assert_close(H.conv5x5_wgrad(x.cuda(), gy.cuda(), stride), gw_ref, CONV_TOL, tag + " wgrad")
         wt = 0.2 * _rand(Cin, Cout, 5, 5, seed=500 + case)
         assert_close(H.convT5x5_fwd(x.cuda(), wt.cuda(), b.cuda(), stride), O.convT5x5(x, wt, b, stride), 3e-6,
                      tag + " convT")
@@ -424,26 +429,28 @@ def test_conv_fwd_bf16x3(H, B, Cin, Cout, Hs, Ws, stride):
     w = torch.randn(Cout, Cin, 5, 5, generator=g) * 0.05
     bias = torch.randn(Cout, generator=g)
     ref = O.conv5x5(x, w, bias, stride)
+    prev_arith = H.CONV_FWD_ARITH
     try:
         H.CONV_FWD_ARITH = "bf16x3"
         y = H.conv5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), stride)
         y2 = H.conv5x5_fwd(x.cuda(), w.cuda(), None, stride)
     finally:
-        H.CONV_FWD_ARITH = "fp32"
+        H.CONV_FWD_ARITH = prev_arith
     assert_close(y, ref, 2e-5, "bf16x3 fwd")
     assert_close(y2, O.conv5x5(x, w, None, stride), 2e-5, "bf16x3 fwd, no bias")
     e32 = rel_l2(H.conv5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), stride), ref)
-    assert e32 <= 3e-6            # the default path is untouched by the switch
+    assert e32 <= CONV_TOL        # the session's own arithmetic is back after the switch
 
 
 def test_conv_fwd_bf16x3_falls_back_when_cin_not_multiple_of_16(H):
     x, w = _rand(2, 3, 16, 16, seed=1), 0.1 * _rand(8, 3, 5, 5, seed=2)
+    prev_arith = H.CONV_FWD_ARITH
     try:
         H.CONV_FWD_ARITH = "bf16x3"
         y = H.conv5x5_fwd(x.cuda(), w.cuda(), None, 2)
     finally:
-        H.CONV_FWD_ARITH = "fp32"
-    assert_close(y, O.conv5x5(x, w, None, 2), 3e-6, "fallback to the fp32 kernel")
+        H.CONV_FWD_ARITH = prev_arith
+    assert_close(y, O.conv5x5(x, w, None, 2), 3e-6, "fallback to the fp32 kernel")   # Cin = 3: always the fp32 kernel
 
 
 @pytest.mark.parametrize("B,Cin,Cout,Hs,Ws,stride", [
@@ -459,19 +466,21 @@ def test_convT_fwd_bf16x3(H, B, Cin, Cout, Hs, Ws, stride):
     w = torch.randn(Cin, Cout, 5, 5, generator=g) * 0.05
     bias = torch.randn(Cout, generator=g)
     ref = O.convT5x5(x, w, bias, stride)
+    prev_arith = H.CONV_FWD_ARITH
     try:
         H.CONV_FWD_ARITH = "bf16x3"
         for variant in (-1, 0, 1, 2, 3):
             lib.vg_debug_set_conv_bf16x3_tile(variant)
             assert_close(H.convT5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), stride), ref, 2e-5, f"bf16x3 convT tile {variant}")
     finally:
-        H.CONV_FWD_ARITH = "fp32"
+        H.CONV_FWD_ARITH = prev_arith
         lib.vg_debug_set_conv_bf16x3_tile(-1)
 
 
 def test_conv_fwd_bf16x3_every_tile(H):
     from disentangle_mlp_amd import _lib
     lib = _lib.load()
+    prev_arith = H.CONV_FWD_ARITH
     try:
         H.CONV_FWD_ARITH = "bf16x3"
         for (B, Cin, Cout, Hs, Ws, s) in ((3, 16, 70, 16, 24, 2), (5, 32, 33, 8, 8, 1), (2, 16, 140, 40, 72, 2)):
@@ -481,7 +490,7 @@ def test_conv_fwd_bf16x3_every_tile(H):
                 lib.vg_debug_set_conv_bf16x3_tile(variant)
                 assert_close(H.conv5x5_fwd(x.cuda(), w.cuda(), None, s), ref, 2e-5, f"bf16x3 fwd tile {variant}")
     finally:
-        H.CONV_FWD_ARITH = "fp32"
+        H.CONV_FWD_ARITH = prev_arith
         lib.vg_debug_set_conv_bf16x3_tile(-1)
 
 
@@ -498,11 +507,12 @@ def test_conv_wgrad_bf16x3(H, B, Cin, Cout, Hs, Ws, stride):
     OH, OW = (Hs - 1) // stride + 1, (Ws - 1) // stride + 1
     gy = torch.randn(B, Cout, OH, OW, generator=g)
     _, gw_ref = O.conv5x5_grads(x, w, gy, stride)
+    prev_arith = H.CONV_FWD_ARITH
     try:
         H.CONV_FWD_ARITH = "bf16x3"
         gw = H.conv5x5_wgrad(x.cuda(), gy.cuda(), stride)
     finally:
-        H.CONV_FWD_ARITH = "fp32"
+        H.CONV_FWD_ARITH = prev_arith
     assert_close(gw, gw_ref, 2e-5, "bf16x3 wgrad")
 
 
@@ -513,9 +523,10 @@ def test_conv_wgrad_bf16x3_unsupported_shape_falls_back(H):
     assert lib.vg_conv5x5_wgrad_bf16x3_workspace_bytes(4, 8, 16, 16, 8, 2) > 0
     x, gy = _rand(2, 3, 10, 10, seed=3), _rand(2, 4, 5, 5, seed=4)
     w = 0.1 * _rand(4, 3, 5, 5, seed=5)
+    prev_arith = H.CONV_FWD_ARITH
     try:
         H.CONV_FWD_ARITH = "bf16x3"
         gw = H.conv5x5_wgrad(x.cuda(), gy.cuda(), 2)
     finally:
-        H.CONV_FWD_ARITH = "fp32"
+        H.CONV_FWD_ARITH = prev_arith
     assert_close(gw, O.conv5x5_grads(x, w, gy, 2)[1], 3e-6, "fallback")
