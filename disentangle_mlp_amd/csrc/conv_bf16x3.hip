@@ -73,6 +73,8 @@ struct XArgs {
   float* y;
   int B, Cin, XH, XW, Cout, CoutP, YH, YW;
   int ntiles_n, tiles_w, tiles_hw, blocks_per_cls;
+  int ksplit, cps;       // forward only: grid-level split of the channel chunks (deep-K, small-grid layers)
+  size_t ysplit;         // elements per partial output slab (then y points at the slabs)
 };
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
@@ -91,7 +93,7 @@ __host__ __device__ constexpr int x_taps_before(int S, int R, int SS) {
 }
 
 template <class C, int R, int SS>
-__device__ __forceinline__ void bf16x3_body(const XArgs& A, f32x4* lds, int bid) {
+__device__ __forceinline__ void bf16x3_body(const XArgs& A, f32x4* lds, int bid, int split) {
   constexpr int MODE = C::MODE, S = C::S, NB = C::NB, TH = C::TH, TW = C::TW, PH = C::PH, PW = C::PW;
   constexpr int COLS = C::COLS, ROWU = C::ROWU, IMGU = C::IMGU, NQ = C::NQ, FC = C::FC, FP = C::FP;
   constexpr int NTMAX = C::NTMAX;
@@ -196,18 +198,19 @@ __device__ __forceinline__ void bf16x3_body(const XArgs& A, f32x4* lds, int bid)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[g][f][r] = 0.f;
 
-  load_chunk(0);
+  const int c_begin = split * A.cps, c_end = min(c_begin + A.cps, nchunks);   // this workgroup's channel chunks
+  load_chunk(c_begin * 16);
   store_chunk();
   bf16x8 a_hi[2][FC], a_lo[2][FC];     // [buffer][fragment]
 #pragma unroll
   for (int g = 0; g < FC; ++g) {
-    a_hi[0][g] = wa[g][0];
-    a_lo[0][g] = wa[g][2 * CoutP];
+    a_hi[0][g] = wa[g][(size_t)c_begin * NTAP * wstep];
+    a_lo[0][g] = wa[g][(size_t)c_begin * NTAP * wstep + 2 * CoutP];
   }
   __syncthreads();
 
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const bool more = (ch + 1) < nchunks;
+  for (int ch = c_begin; ch < c_end; ++ch) {
+    const bool more = (ch + 1) < c_end;
     if (more) load_chunk((ch + 1) * 16);
     // one filter row (NTW taps) per trip of a rolled loop: keeps the filter prefetch one tap deep
     // (fully unrolled, hipcc hoists every tap's loads and spills).  When NTW is odd the prefetched
@@ -273,14 +276,14 @@ __device__ __forceinline__ void bf16x3_body(const XArgs& A, f32x4* lds, int bid)
     const int oh = (MODE == X_FWD) ? th : S * th + R;
     const int ow = (MODE == X_FWD) ? tw : S * tw + SS;
     const bool pok = b < A.B && oh < YH && ow < YW;
-    float* yb = A.y + ((size_t)b * Cout * YH + oh) * YW + ow;
+    float* yb = A.y + (size_t)split * A.ysplit + ((size_t)b * Cout * YH + oh) * YW + ow;
 #pragma unroll
     for (int g = 0; g < FC; ++g) {
       float bv[16];
 #pragma unroll
       for (int r16 = 0; r16 < 16; ++r16) {
         const int co = min(n0 + (wc * FC + g) * 32 + acc_row(r16, lane), Cout - 1);
-        bv[r16] = A.bias ? A.bias[co] : 0.f;
+        bv[r16] = (A.bias && split == 0) ? A.bias[co] : 0.f;     // partial slabs: the bias goes in once
       }
 #pragma unroll
       for (int r16 = 0; r16 < 16; ++r16) {
@@ -296,18 +299,25 @@ __global__ __launch_bounds__(XNT, 2) void conv5x5_bf16x3_kernel(XArgs A) {
   __shared__ f32x4 lds[4 * C::IMGU];     // [plane][k-block][image][row][(parity)][column]
   int bid = blockIdx.x;
   if constexpr (C::NCLS == 1) {
-    bf16x3_body<C, 0, 0>(A, lds, bid);
+    const int split = bid / A.blocks_per_cls;
+    bf16x3_body<C, 0, 0>(A, lds, bid - split * A.blocks_per_cls, split);
   } else {
     const int cls = bid / A.blocks_per_cls;   // class 0 (3x3 taps) first: longest blocks start earliest
     bid -= cls * A.blocks_per_cls;
     switch (cls) {
-      case 0: bf16x3_body<C, 0, 0>(A, lds, bid); break;
-      case 1: bf16x3_body<C, 0, 1>(A, lds, bid); break;
-      case 2: bf16x3_body<C, 1, 0>(A, lds, bid); break;
-      default: bf16x3_body<C, 1, 1>(A, lds, bid); break;
+      case 0: bf16x3_body<C, 0, 0>(A, lds, bid, 0); break;
+      case 1: bf16x3_body<C, 0, 1>(A, lds, bid, 0); break;
+      case 2: bf16x3_body<C, 1, 0>(A, lds, bid, 0); break;
+      default: bf16x3_body<C, 1, 1>(A, lds, bid, 0); break;
     }
   }
 }
+
+struct XSplit {
+  int k;          // 1: no split
+  float* slabs;   // k partial outputs
+};
+XSplit g_xsplit = {1, nullptr};   // set by the forward entry point around its dispatch (one host thread per process)
 
 template <class C>
 int launch_x(const float* x, const bf16x8* w, const float* bias, float* y, int B, int Cin, int XH, int XW, int Cout,
@@ -327,15 +337,24 @@ int launch_x(const float* x, const bf16x8* w, const float* bias, float* y, int B
   A.tiles_hw = cdiv(tsh, C::TH) * A.tiles_w;
   A.ntiles_n = cdiv(Cout, C::TN);
   const long per_cls = (long)A.ntiles_n * A.tiles_hw * cdiv(B, C::NB);
-  const long grid = per_cls * C::NCLS;
+  const int ksplit = (C::MODE == X_FWD) ? g_xsplit.k : 1;
+  const long grid = per_cls * C::NCLS * ksplit;
   if (grid <= 0 || grid > 0x7fffffffL) return VG_ERR_BAD_ARG;
   A.blocks_per_cls = (int)per_cls;
+  A.ksplit = ksplit;
+  A.cps = cdiv(Cin / 16, ksplit);
+  A.ysplit = (size_t)B * Cout * A.YH * A.YW;
+  if (ksplit > 1) A.y = g_xsplit.slabs;
   hipLaunchKernelGGL(conv5x5_bf16x3_kernel<C>, dim3((unsigned)grid), dim3(XNT), 0, st, A);
   VG_CHECK_LAUNCH();
+  if (ksplit > 1) {
+    if (A.ysplit > 0x7fffffffUL) return VG_ERR_BAD_ARG;
+    return vg_internal_wgrad_reduce(g_xsplit.slabs, y, (int)A.ysplit, ksplit, st);   // fixed-order sum of the slabs
+  }
   return 0;
 }
 
-int g_x_tile_override = -1;   // diagnostics: 0 = 128 cout x 128 px, 1 = 64 x 128, 2 = 64 x 64, 3 = 32 cout x 128 px
+int g_x_tile_override = -1;   // diagnostics: 0 = 128 cout x 128 px, 1 = 64 x 128, 2 = 64 x 64, 3 = 32 cout x 128 px, 4 = 32 x 256 (transposed)
 
 template <int MODE, int S, int WC, int FC, int FP>
 int dispatch_geom(const float* x, const bf16x8* w, const float* bias, float* y, int B, int Cin, int XH, int XW,
@@ -346,6 +365,10 @@ int dispatch_geom(const float* x, const bf16x8* w, const float* bias, float* y, 
     if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 4, 32, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
     if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 8, 16, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
     return launch_x<XCfg<MODE, S, 2, 8, 8, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+  } else if constexpr (TM == 256) {
+    if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 8, 32, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 16, 16, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    return launch_x<XCfg<MODE, S, 4, 8, 8, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
   } else {
     if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 2, 32, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
     if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 4, 16, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
@@ -362,13 +385,18 @@ int dispatch_x(const float* x, const bf16x8* w, const float* bias, float* y, int
   const int ncls = (MODE == X_TR) ? S * S : 1;
   const long px128 = (long)cdiv(B * cdiv(tsh, 8) * cdiv(tsw, 8) * 64, 128) * ncls;
   int var = 2;
-  if (Cout <= 32) var = 3;
+  if (Cout <= 32) var = (MODE == X_TR && px128 >= 1024) ? 4 : 3;      // transposed, large grid: 256 pixels per workgroup
   else if (MODE == X_FWD && Cout > 64 && px128 * cdiv(Cout, 128) >= 512) var = 0;   // transposed: 64 x 128 measured faster
   else if (px128 * cdiv(Cout, 64) >= 512) var = 1;
-  if (g_x_tile_override >= 0 && g_x_tile_override <= 3) var = g_x_tile_override;
+  if (MODE == X_FWD && g_xsplit.k > 1) var = 0;             // split-K is sized for the 128 x 128 tile
+  else if (g_x_tile_override >= 0 && g_x_tile_override <= 4 && !(g_x_tile_override == 4 && MODE == X_FWD))
+    var = g_x_tile_override;
   if (var == 0) return dispatch_geom<MODE, S, 2, 2, 2>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
   if (var == 1) return dispatch_geom<MODE, S, 2, 1, 2>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
   if (var == 3) return dispatch_geom<MODE, S, 1, 1, 1>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+  if constexpr (MODE == X_TR) {
+    if (var == 4) return dispatch_geom<MODE, S, 1, 1, 2>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+  }
   return dispatch_geom<MODE, S, 2, 1, 1>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
 }
 
@@ -424,6 +452,18 @@ __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float* __restric
   }
 }
 
+// Forward, deep K on a small grid (the 8 x 8-pixel layers): the 128 x 128 tile with the channel chunks split
+// over k workgroups, partial outputs summed in a fixed order.  1 = no split.
+int fwd_ksplit(int B, int Cin, int H, int W, int Cout, int S) {
+  if (g_x_tile_override >= 0) return 1;
+  const int tsw = (W - 1) / S + 1, tsh = (H - 1) / S + 1, nchunks = Cin / 16;
+  const long wgs = (long)cdiv(B * cdiv(tsh, 8) * cdiv(tsw, 8) * 64, 128) * cdiv(Cout, 128);
+  if (Cout <= 64 || wgs >= 512 || nchunks < 8) return 1;
+  int k = 2;     // every split must own at least one chunk: (k - 1) * ceil(nchunks / k) < nchunks
+  while (wgs * k < 512 && k < 8 && nchunks / (2 * k) >= 2 && (2 * k - 1) * cdiv(nchunks, 2 * k) < nchunks) k *= 2;
+  return k;
+}
+
 int x_args_ok(const float* x, const void* packed, float* y, int B, int Cin, int H, int W, int Cout, int stride) {
   if (!x || !packed || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
   return (stride == 1 || stride == 2) && Cin % 16 == 0 && ((uintptr_t)packed & 15) == 0;
@@ -452,13 +492,27 @@ extern "C" int vg_conv5x5_pack_bf16x3(const float* w, void* packed, int Cout, in
   return 0;
 }
 
+extern "C" size_t vg_conv5x5_fwd_bf16x3_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride) {
+  if (B <= 0 || Cin <= 0 || Cin % 16 || Cout <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return 0;
+  const int k = fwd_ksplit(B, Cin, H, W, Cout, stride);
+  if (k <= 1) return 0;
+  return (size_t)k * B * Cout * ((H - 1) / stride + 1) * ((W - 1) / stride + 1) * sizeof(float);
+}
+
 extern "C" int vg_conv5x5_fwd_bf16x3(const float* x, const void* packed, const float* bias, float* y, int B, int Cin,
-                                     int H, int W, int Cout, int stride, void* stream) {
+                                     int H, int W, int Cout, int stride, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
   if (!x_args_ok(x, packed, y, B, Cin, H, W, Cout, stride)) return VG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   const bf16x8* w = (const bf16x8*)packed;
-  if (stride == 2) return dispatch_x<X_FWD, 2>(x, w, bias, y, B, Cin, H, W, Cout, st);
-  return dispatch_x<X_FWD, 1>(x, w, bias, y, B, Cin, H, W, Cout, st);
+  const int k = fwd_ksplit(B, Cin, H, W, Cout, stride);
+  if (k > 1 && (!workspace || workspace_bytes < vg_conv5x5_fwd_bf16x3_workspace_bytes(B, Cin, H, W, Cout, stride)))
+    return VG_ERR_WORKSPACE;
+  g_xsplit = {k, (float*)workspace};
+  const int rc = (stride == 2) ? dispatch_x<X_FWD, 2>(x, w, bias, y, B, Cin, H, W, Cout, st)
+                               : dispatch_x<X_FWD, 1>(x, w, bias, y, B, Cin, H, W, Cout, st);
+  g_xsplit = {1, nullptr};
+  return rc;
 }
 
 extern "C" int vg_convT5x5_fwd_bf16x3(const float* x, const void* packed, const float* bias, float* y, int B, int Cin,

@@ -186,9 +186,12 @@ def conv5x5_fwd(x, w, bias, stride):
     y = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
     if CONV_FWD_ARITH == "bf16x3" and Cin % 16 == 0:
         pk = _packed_filter(lib, w, Cout, Cin, 2, 1)
+        need = lib.vg_conv5x5_fwd_bf16x3_workspace_bytes(B, Cin, H, W, Cout, stride)    # split-K slabs, deep-K layers only
+        ws = workspace(need, x.device) if need else None
         with _timed(("conv_fwd", B, Cin, H, W, Cout, stride)):
             check(lib.vg_conv5x5_fwd_bf16x3(x.data_ptr(), pk.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W,
-                                            Cout, stride, _stream()), "vg_conv5x5_fwd_bf16x3")
+                                            Cout, stride, _ptr(ws), ws.numel() if need else 0, _stream()),
+                  "vg_conv5x5_fwd_bf16x3")
         return y
     if USE_PACKED_FILTERS:
         pk = _packed_filter(lib, w, Cout, Cin, 0, stride)

@@ -93,8 +93,10 @@ int vg_debug_set_conv_bf16x3_tile(int variant);   /* tuning only: 0 = 128x128, 1
 size_t vg_conv5x5_packed_bf16x3_bytes(int Cout, int Cin);
 int vg_conv5x5_pack_bf16x3(const float* w, void* packed, int Cout, int Cin, int transposed, int stride,
                            void* stream);
+size_t vg_conv5x5_fwd_bf16x3_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride);   /* 0 for most shapes */
 int vg_conv5x5_fwd_bf16x3(const float* x, const void* packed, const float* bias, float* y,
-                          int B, int Cin, int H, int W, int Cout, int stride, void* stream);
+                          int B, int Cin, int H, int W, int Cout, int stride,
+                          void* workspace, size_t workspace_bytes, void* stream);
 int vg_convT5x5_fwd_bf16x3(const float* x, const void* packed, const float* bias, float* y,
                            int B, int Cin, int H, int W, int Cout, int stride, void* stream);
 /* vg_conv5x5_wgrad in the same opt-in arithmetic.  The reduction runs over images in groups of 16

@@ -469,7 +469,7 @@ def test_convT_fwd_bf16x3(H, B, Cin, Cout, Hs, Ws, stride):
     prev_arith = H.CONV_FWD_ARITH
     try:
         H.CONV_FWD_ARITH = "bf16x3"
-        for variant in (-1, 0, 1, 2, 3):
+        for variant in (-1, 0, 1, 2, 3, 4):
             lib.vg_debug_set_conv_bf16x3_tile(variant)
             assert_close(H.convT5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), stride), ref, 2e-5, f"bf16x3 convT tile {variant}")
     finally:
@@ -530,3 +530,24 @@ def test_conv_wgrad_bf16x3_unsupported_shape_falls_back(H):
     finally:
         H.CONV_FWD_ARITH = prev_arith
     assert_close(gw, O.conv5x5_grads(x, w, gy, 2)[1], 3e-6, "fallback")
+
+
+def test_conv_fwd_bf16x3_split_k(H):
+    """Deep-K layers on a small grid run the 128 x 128 tile with the channel chunks split over 2-8
+    workgroups and a fixed-order sum of the partial outputs (bias added once)."""
+    from disentangle_mlp_amd import _lib
+    lib = _lib.load()
+    for (B, Cin, Cout, Hs, s) in ((16, 256, 256, 16, 2), (8, 144, 200, 8, 1), (32, 128, 130, 16, 2)):
+        assert lib.vg_conv5x5_fwd_bf16x3_workspace_bytes(B, Cin, Hs, Hs, Cout, s) > 0, (B, Cin, Cout)
+        g = torch.Generator().manual_seed(13)
+        x = torch.randn(B, Cin, Hs, Hs, generator=g)
+        w = torch.randn(Cout, Cin, 5, 5, generator=g) * 0.03
+        bias = torch.randn(Cout, generator=g)
+        prev_arith = H.CONV_FWD_ARITH
+        try:
+            H.CONV_FWD_ARITH = "bf16x3"
+            y = H.conv5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), s)
+        finally:
+            H.CONV_FWD_ARITH = prev_arith
+        assert_close(y, O.conv5x5(x, w, bias, s), 2e-5, f"split-K {B} {Cin} {Cout}")
+    assert lib.vg_conv5x5_fwd_bf16x3_workspace_bytes(128, 128, 32, 32, 256, 2) == 0      # large grid: no split
