@@ -148,28 +148,34 @@ def main():
     elapsed = time.perf_counter() - t0
     dom_ms = ops.stop_timing().get(dominant, [])
 
-    # ---- informational: the same K steps in the opt-in bf16x3 arithmetic (N = 1 only; NOT `value`)
+    # ---- informational: the same K steps in the two opt-in split-bf16 arithmetics (N = 1 only; NOT `value`)
     opt_in = None
     if world == 1 and arith == "fp32" and not args.no_opt_in:
-        ops.CONV_FWD_ARITH = "bf16x3"
+        opt_in = {}
+        notes = {"bf16x6": ("every fp32 operand split exactly into 3 bf16 planes (8+8+8 mantissa bits), 6 bf16 MFMAs per "
+                            "multiply, fp32 accumulate: fp32-equivalent -- the whole GPU test suite passes at the fp32 "
+                            "tolerances with VG_CONV_ARITH=bf16x6", 8.6e-7),
+                 "bf16x3": ("operands split into 2 bf16 planes (hi/lo), 3 bf16 MFMAs per multiply, fp32 accumulate; "
+                            "tests hold it to 2e-5 per convolution", 4.5e-6)}
         try:
-            for _ in range(2):
-                one_step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                out2 = one_step()
-            torch.cuda.synchronize()
-            e2 = time.perf_counter() - t1
-            opt_in = {"value": round(B * args.steps / e2, 2), "unit": "images/s", "ms_per_step": round(e2 / args.steps * 1e3, 3),
-                      "dtype": "bf16x3 (conv fwd / dgrad / wgrad: hi/lo-split operands, 3 bf16 MFMAs per product, fp32 "
-                               "accumulate) + fp32 (3-channel layers, everything else)",
-                      "conv_rel_error_vs_fp64": 4.5e-6, "default": False,
-                      "losses_finite": all(bool(torch.isfinite(v).all()) for v in out2.values()),
-                      "note": "ops.CONV_FWD_ARITH / VG_CONV_ARITH=bf16x3; tests hold it to 2e-5 per convolution "
-                              "(tests/test_kernels_gpu.py); not the headline: `value` is the exact-fp32 path"}
+            for mode in ("bf16x6", "bf16x3"):
+                ops.CONV_FWD_ARITH = mode
+                for _ in range(2):
+                    one_step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    out2 = one_step()
+                torch.cuda.synchronize()
+                e2 = time.perf_counter() - t1
+                opt_in[mode] = {"value": round(B * args.steps / e2, 2), "unit": "images/s",
+                                "ms_per_step": round(e2 / args.steps * 1e3, 3),
+                                "arithmetic": notes[mode][0], "conv_rel_error_vs_fp64": notes[mode][1],
+                                "losses_finite": all(bool(torch.isfinite(v).all()) for v in out2.values())}
         finally:
             ops.CONV_FWD_ARITH = "fp32"
+        opt_in["note"] = ("ops.CONV_FWD_ARITH / VG_CONV_ARITH; not the headline: `value` is the exact-fp32-MFMA path "
+                          "(conv rel. error vs fp64 5e-7..1e-6)")
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -185,12 +191,13 @@ def main():
             avg_ms = sum(dom_ms) / len(dom_ms)
             ach = conv_flops(dominant) / (avg_ms * 1e-3) / 1e12
             traffic, tsrc = pmc_traffic(dominant)
-            x3 = arith == "bf16x3" and dominant[0] != "conv_wgrad" and dominant[2] % 16 == 0
+            x3 = arith != "fp32" and dominant[0] != "conv_wgrad" and dominant[2] % 16 == 0
+            nprod = 6 if arith == "bf16x6" else 3
             peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": None if x3 else traffic, "traffic_unit": "bytes/launch",
                     "traffic_source": None if x3 else tsrc,
-                    "kernel": ("conv5x5_bf16x3_kernel (3 bf16 MFMAs per product: effective peak %.0f)" % (peak / 3)) if x3
+                    "kernel": ("conv5x5_bf16x3_kernel (%d bf16 MFMAs per product: effective peak %.0f)" % (nprod, peak / nprod)) if x3
                     else ("conv5x5_igemm_kernel" if dominant[0] != "conv_wgrad" else "conv5x5_wgrad_kernel"),
                     "launch": {"op": dominant[0], "B": dominant[1], "Cin": dominant[2], "H": dominant[3],
                                "W": dominant[4], "Cout": dominant[5], "stride": dominant[6]},
@@ -200,7 +207,7 @@ def main():
             "metric": "celeba64_betavaegan_train_images_per_sec", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp32" if arith == "fp32" else "bf16x3 (convolutions: hi/lo-split operands on the bf16 MFMA, "
+            "dtype": "fp32" if arith == "fp32" else arith + " (convolutions: split-bf16 operands on the bf16 MFMA, "
                                                     "fp32 accumulate) + fp32 (3-channel layers, everything else)",
             "data": "synthetic",
             "config": {"workload": "new_betavaegan.py beta=25 VAE-GAN iteration (D + decoder + encoder phases, "
@@ -215,7 +222,7 @@ def main():
             "losses_finite": finite,
         }
         if world == 1 and arith == "fp32" and not args.no_opt_in:
-            res["opt_in_bf16x3"] = opt_in
+            res["opt_in"] = opt_in
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(B, args.beta)
         print(json.dumps(res), flush=True)

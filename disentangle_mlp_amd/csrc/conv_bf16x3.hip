@@ -48,9 +48,12 @@ constexpr int row_units(int mode, int S, int TW, int PW) {
 }
 
 // WC x WP wavefronts (WC * WP = 4), FC x FP fragments each: cout tile 32*WC*FC, pixel tile 32*WP*FP
-template <int MODE_, int S_, int NB_, int TH_, int TW_, int WC_, int FC_, int FP_>
+// NP_: operand planes -- 2: hi/lo split, 3 products ("bf16x3", ~4.5e-6); 3: exact hi/mid/lo split of the fp32
+// mantissa (8 + 8 + 8 bits), 6 products, every dropped term below 2^-24 ("bf16x6", fp32-equivalent)
+template <int MODE_, int S_, int NB_, int TH_, int TW_, int WC_, int FC_, int FP_, int NP_>
 struct XCfg {
   static constexpr int MODE = MODE_, S = S_, NB = NB_, TH = TH_, TW = TW_, WC = WC_, WP = 4 / WC_, FC = FC_, FP = FP_;
+  static constexpr int NP = NP_;
   static constexpr int TN = 32 * WC * FC, TM = NB * TH * TW;
   static constexpr int NTMAX = (MODE == X_FWD) ? 5 : (5 + S - 1) / S;
   static constexpr int PH = (MODE == X_FWD) ? S * (TH - 1) + 5 : TH + NTMAX - 1;
@@ -95,7 +98,7 @@ __host__ __device__ constexpr int x_taps_before(int S, int R, int SS) {
 template <class C, int R, int SS>
 __device__ __forceinline__ void bf16x3_body(const XArgs& A, f32x4* lds, int bid, int split) {
   constexpr int MODE = C::MODE, S = C::S, NB = C::NB, TH = C::TH, TW = C::TW, PH = C::PH, PW = C::PW;
-  constexpr int COLS = C::COLS, ROWU = C::ROWU, IMGU = C::IMGU, NQ = C::NQ, FC = C::FC, FP = C::FP;
+  constexpr int COLS = C::COLS, ROWU = C::ROWU, IMGU = C::IMGU, NQ = C::NQ, FC = C::FC, FP = C::FP, NP = C::NP;
   constexpr int NTMAX = C::NTMAX;
   constexpr int NTH = (MODE == X_FWD) ? 5 : (5 - R + S - 1) / S;   // taps along h / w in this class
   constexpr int NTW = (MODE == X_FWD) ? 5 : (5 - SS + S - 1) / S;
@@ -158,17 +161,20 @@ __device__ __forceinline__ void bf16x3_body(const XArgs& A, f32x4* lds, int bid,
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const bool ok = (pvalid >> q) & 1u;
-      bf16x8 hi, lo;
+      bf16x8 pl[NP];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float v = ok ? preg[q][j] : 0.f;
-        const __bf16 h = (__bf16)v;
-        hi[j] = h;
-        lo[j] = (__bf16)(v - (float)h);
+        float v = ok ? preg[q][j] : 0.f;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {          // hi, (mid,) lo: each plane takes the leading 8 bits of what is left
+          const __bf16 h = (__bf16)v;
+          pl[p][j] = h;
+          v -= (float)h;
+        }
       }
       if (pdst[q] >= 0) {
-        lds[pdst[q]] = __builtin_bit_cast(f32x4, hi);
-        lds[pdst[q] + 2 * IMGU] = __builtin_bit_cast(f32x4, lo);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) lds[pdst[q] + p * 2 * IMGU] = __builtin_bit_cast(f32x4, pl[p]);
       }
     }
   };
@@ -183,7 +189,7 @@ __device__ __forceinline__ void bf16x3_body(const XArgs& A, f32x4* lds, int bid,
     base_b[f] = kb * IMGU + (nb * PH + PSTEP * (r / TW)) * ROWU + (C::SPLIT ? (r % TW) : PSTEP * (r % TW));
   }
   const int CoutP = A.CoutP;
-  const size_t wstep = (size_t)4 * CoutP;    // units per (chunk, tap) step
+  const size_t wstep = (size_t)2 * NP * CoutP;    // units per (chunk, tap) step
   const int nchunks = Cin / 16;
   const bf16x8* wa[FC];                      // this class' first step, this lane's cout and k-block
 #pragma unroll
@@ -201,12 +207,11 @@ __device__ __forceinline__ void bf16x3_body(const XArgs& A, f32x4* lds, int bid,
   const int c_begin = split * A.cps, c_end = min(c_begin + A.cps, nchunks);   // this workgroup's channel chunks
   load_chunk(c_begin * 16);
   store_chunk();
-  bf16x8 a_hi[2][FC], a_lo[2][FC];     // [buffer][fragment]
+  bf16x8 av[2][FC][NP];     // [buffer][fragment][plane]
 #pragma unroll
-  for (int g = 0; g < FC; ++g) {
-    a_hi[0][g] = wa[g][(size_t)c_begin * NTAP * wstep];
-    a_lo[0][g] = wa[g][(size_t)c_begin * NTAP * wstep + 2 * CoutP];
-  }
+  for (int g = 0; g < FC; ++g)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) av[0][g][p] = wa[g][(size_t)c_begin * NTAP * wstep + (size_t)p * 2 * CoutP];
   __syncthreads();
 
   for (int ch = c_begin; ch < c_end; ++ch) {
@@ -226,37 +231,31 @@ __device__ __forceinline__ void bf16x3_body(const XArgs& A, f32x4* lds, int bid,
         const int cur = tb & 1, nxt = cur ^ 1;
         // next tap's filter fragments (the pack has one spare step after the last one)
 #pragma unroll
-        for (int g = 0; g < FC; ++g) {
-          a_hi[nxt][g] = wrow[g][(size_t)(tb + 1) * wstep];
-          a_lo[nxt][g] = wrow[g][(size_t)(tb + 1) * wstep + 2 * CoutP];
-        }
+        for (int g = 0; g < FC; ++g)
+#pragma unroll
+          for (int p = 0; p < NP; ++p) av[nxt][g][p] = wrow[g][(size_t)(tb + 1) * wstep + (size_t)p * 2 * CoutP];
         const int imm = (MODE == X_TR) ? (NTMAX - 1 - tb) : (C::SPLIT ? (tb & 1) * COLS + (tb >> 1) : tb);
-        bf16x8 b_hi[FP], b_lo[FP];
+        bf16x8 bv[FP][NP];
 #pragma unroll
-        for (int f = 0; f < FP; ++f) {
-          b_hi[f] = __builtin_bit_cast(bf16x8, lds[base_b[f] + rowoff + imm]);
-          b_lo[f] = __builtin_bit_cast(bf16x8, lds[base_b[f] + rowoff + imm + 2 * IMGU]);
-        }
-        // small terms first, product-major: independent accumulators between dependent MFMAs
+        for (int f = 0; f < FP; ++f)
 #pragma unroll
-        for (int g = 0; g < FC; ++g)
+          for (int p = 0; p < NP; ++p) bv[f][p] = __builtin_bit_cast(bf16x8, lds[base_b[f] + rowoff + imm + p * 2 * IMGU]);
+        // products with plane index sum <= NP - 1, smallest terms first; product-major so that independent
+        // accumulators sit between dependent MFMAs
 #pragma unroll
-          for (int f = 0; f < FP; ++f) acc[g][f] = mfma_bf16(a_lo[cur][g], b_hi[f], acc[g][f]);
+        for (int sum = NP - 1; sum >= 0; --sum)
 #pragma unroll
-        for (int g = 0; g < FC; ++g)
+          for (int pa = sum; pa >= 0; --pa)
 #pragma unroll
-          for (int f = 0; f < FP; ++f) acc[g][f] = mfma_bf16(a_hi[cur][g], b_lo[f], acc[g][f]);
+            for (int g = 0; g < FC; ++g)
 #pragma unroll
-        for (int g = 0; g < FC; ++g)
-#pragma unroll
-          for (int f = 0; f < FP; ++f) acc[g][f] = mfma_bf16(a_hi[cur][g], b_hi[f], acc[g][f]);
+              for (int f = 0; f < FP; ++f) acc[g][f] = mfma_bf16(av[cur][g][pa], bv[f][sum - pa], acc[g][f]);
       }
       if (NTW & 1) {
 #pragma unroll
-        for (int g = 0; g < FC; ++g) {
-          a_hi[0][g] = a_hi[1][g];
-          a_lo[0][g] = a_lo[1][g];
-        }
+        for (int g = 0; g < FC; ++g)
+#pragma unroll
+          for (int p = 0; p < NP; ++p) av[0][g][p] = av[1][g][p];
       }
     }
     __syncthreads();
@@ -296,7 +295,7 @@ __device__ __forceinline__ void bf16x3_body(const XArgs& A, f32x4* lds, int bid,
 
 template <class C>
 __global__ __launch_bounds__(XNT, 2) void conv5x5_bf16x3_kernel(XArgs A) {
-  __shared__ f32x4 lds[4 * C::IMGU];     // [plane][k-block][image][row][(parity)][column]
+  __shared__ f32x4 lds[2 * C::NP * C::IMGU];     // [plane][k-block][image][row][(parity)][column]
   int bid = blockIdx.x;
   if constexpr (C::NCLS == 1) {
     const int split = bid / A.blocks_per_cls;
@@ -356,29 +355,29 @@ int launch_x(const float* x, const bf16x8* w, const float* bias, float* y, int B
 
 int g_x_tile_override = -1;   // diagnostics: 0 = 128 cout x 128 px, 1 = 64 x 128, 2 = 64 x 64, 3 = 32 cout x 128 px, 4 = 32 x 256 (transposed)
 
-template <int MODE, int S, int WC, int FC, int FP>
+template <int MODE, int S, int WC, int FC, int FP, int NP>
 int dispatch_geom(const float* x, const bf16x8* w, const float* bias, float* y, int B, int Cin, int XH, int XW,
                   int Cout, hipStream_t st) {
   const int tsw = (MODE == X_FWD) ? (XW - 1) / S + 1 : XW;
   constexpr int TM = 32 * (4 / WC) * FP;
   if constexpr (TM == 128) {
-    if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 4, 32, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 8, 16, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    return launch_x<XCfg<MODE, S, 2, 8, 8, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 4, 32, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 8, 16, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    return launch_x<XCfg<MODE, S, 2, 8, 8, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
   } else if constexpr (TM == 256) {
-    if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 8, 32, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 16, 16, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    return launch_x<XCfg<MODE, S, 4, 8, 8, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 8, 32, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 16, 16, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    return launch_x<XCfg<MODE, S, 4, 8, 8, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
   } else {
-    if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 2, 32, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 4, 16, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    return launch_x<XCfg<MODE, S, 1, 8, 8, WC, FC, FP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 2, 32, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 4, 16, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    return launch_x<XCfg<MODE, S, 1, 8, 8, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
   }
 }
 
 // Biggest tile that still gives every CU two workgroups (256 CUs): 128 cout x 128 px, else 64 cout x
 // 128 px, else 64 x 64; 32 cout x 128 px (4 wavefronts along the pixels) for thin outputs.
-template <int MODE, int S>
+template <int MODE, int S, int NP>
 int dispatch_x(const float* x, const bf16x8* w, const float* bias, float* y, int B, int Cin, int XH, int XW, int Cout,
                hipStream_t st) {
   const int tsw = (MODE == X_FWD) ? (XW - 1) / S + 1 : XW, tsh = (MODE == X_FWD) ? (XH - 1) / S + 1 : XH;
@@ -391,13 +390,13 @@ int dispatch_x(const float* x, const bf16x8* w, const float* bias, float* y, int
   if (MODE == X_FWD && g_xsplit.k > 1) var = 0;             // split-K is sized for the 128 x 128 tile
   else if (g_x_tile_override >= 0 && g_x_tile_override <= 4 && !(g_x_tile_override == 4 && MODE == X_FWD))
     var = g_x_tile_override;
-  if (var == 0) return dispatch_geom<MODE, S, 2, 2, 2>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-  if (var == 1) return dispatch_geom<MODE, S, 2, 1, 2>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-  if (var == 3) return dispatch_geom<MODE, S, 1, 1, 1>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+  if (var == 0) return dispatch_geom<MODE, S, 2, 2, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+  if (var == 1) return dispatch_geom<MODE, S, 2, 1, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+  if (var == 3) return dispatch_geom<MODE, S, 1, 1, 1, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
   if constexpr (MODE == X_TR) {
-    if (var == 4) return dispatch_geom<MODE, S, 1, 1, 2>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    if (var == 4) return dispatch_geom<MODE, S, 1, 1, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
   }
-  return dispatch_geom<MODE, S, 2, 1, 1>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+  return dispatch_geom<MODE, S, 2, 1, 1, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
 }
 
 // packed[class][chunk][tap][plane][k-block][CoutP] x 8 bf16 (+ one zero step at the end).
@@ -406,7 +405,7 @@ int dispatch_x(const float* x, const bf16x8* w, const float* bias, float* y, int
 //                   (kh, kw) = (R + S*a, SS + S*b).
 __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float* __restrict__ w, bf16x8* __restrict__ p,
                                                          int Cout, int Cin, int CoutP, int nsteps, int transposed,
-                                                         int S) {
+                                                         int S, int planes) {
   const int co = blockIdx.x * 256 + threadIdx.x;
   const int s = blockIdx.y;                 // step; s == nsteps is the spare
   if (co >= CoutP) return;
@@ -437,18 +436,23 @@ __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float* __restric
   }
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
-    bf16x8 hi, lo;
+    float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int ci = c16 * 16 + kb * 8 + j;
-      float v = 0.f;
-      if (live) v = transposed ? w[((size_t)ci * Cout + co) * 25 + kh * 5 + kw] : w[((size_t)co * Cin + ci) * 25 + kh * 5 + kw];
-      const __bf16 h = (__bf16)v;
-      hi[j] = h;
-      lo[j] = (__bf16)(v - (float)h);
+      v[j] = 0.f;
+      if (live) v[j] = transposed ? w[((size_t)ci * Cout + co) * 25 + kh * 5 + kw] : w[((size_t)co * Cin + ci) * 25 + kh * 5 + kw];
     }
-    p[((size_t)s * 4 + kb) * CoutP + co] = hi;
-    p[((size_t)s * 4 + 2 + kb) * CoutP + co] = lo;
+    for (int pl = 0; pl < planes; ++pl) {       // hi, (mid,) lo
+      bf16x8 q;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)v[j];
+        q[j] = h;
+        v[j] -= (float)h;
+      }
+      p[((size_t)s * planes * 2 + pl * 2 + kb) * CoutP + co] = q;
+    }
   }
 }
 
@@ -464,9 +468,10 @@ int fwd_ksplit(int B, int Cin, int H, int W, int Cout, int S) {
   return k;
 }
 
-int x_args_ok(const float* x, const void* packed, float* y, int B, int Cin, int H, int W, int Cout, int stride) {
+int x_args_ok(const float* x, const void* packed, float* y, int B, int Cin, int H, int W, int Cout, int stride,
+              int planes) {
   if (!x || !packed || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
-  return (stride == 1 || stride == 2) && Cin % 16 == 0 && ((uintptr_t)packed & 15) == 0;
+  return (stride == 1 || stride == 2) && Cin % 16 == 0 && ((uintptr_t)packed & 15) == 0 && (planes == 2 || planes == 3);
 }
 
 }  // namespace
@@ -476,18 +481,18 @@ extern "C" int vg_debug_set_conv_bf16x3_tile(int variant) {
   return 0;
 }
 
-extern "C" size_t vg_conv5x5_packed_bf16x3_bytes(int Cout, int Cin) {
-  if (Cout <= 0 || Cin <= 0 || Cin % 16) return 0;
-  return (size_t)(Cin / 16 * 25 + 1) * 4 * ((Cout + 127) & ~127) * 16;
+extern "C" size_t vg_conv5x5_packed_bf16x3_bytes(int Cout, int Cin, int planes) {
+  if (Cout <= 0 || Cin <= 0 || Cin % 16 || (planes != 2 && planes != 3)) return 0;
+  return (size_t)(Cin / 16 * 25 + 1) * 2 * planes * ((Cout + 127) & ~127) * 16;
 }
 
 extern "C" int vg_conv5x5_pack_bf16x3(const float* w, void* packed, int Cout, int Cin, int transposed, int stride,
-                                      void* stream) {
+                                      int planes, void* stream) {
   if (!w || !packed || Cout <= 0 || Cin <= 0 || Cin % 16 || ((uintptr_t)packed & 15)) return VG_ERR_BAD_ARG;
-  if (stride != 1 && stride != 2) return VG_ERR_BAD_ARG;
+  if ((stride != 1 && stride != 2) || (planes != 2 && planes != 3)) return VG_ERR_BAD_ARG;
   const int CoutP = (Cout + 127) & ~127, nsteps = Cin / 16 * 25;
   hipLaunchKernelGGL(pack_bf16x3_kernel, dim3(cdiv(CoutP, 256), nsteps + 1), dim3(256), 0, (hipStream_t)stream, w,
-                     (bf16x8*)packed, Cout, Cin, CoutP, nsteps, transposed ? 1 : 0, transposed ? stride : 1);
+                     (bf16x8*)packed, Cout, Cin, CoutP, nsteps, transposed ? 1 : 0, transposed ? stride : 1, planes);
   VG_CHECK_LAUNCH();
   return 0;
 }
@@ -500,26 +505,35 @@ extern "C" size_t vg_conv5x5_fwd_bf16x3_workspace_bytes(int B, int Cin, int H, i
 }
 
 extern "C" int vg_conv5x5_fwd_bf16x3(const float* x, const void* packed, const float* bias, float* y, int B, int Cin,
-                                     int H, int W, int Cout, int stride, void* workspace, size_t workspace_bytes,
-                                     void* stream) {
-  if (!x_args_ok(x, packed, y, B, Cin, H, W, Cout, stride)) return VG_ERR_BAD_ARG;
+                                     int H, int W, int Cout, int stride, int planes, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  if (!x_args_ok(x, packed, y, B, Cin, H, W, Cout, stride, planes)) return VG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   const bf16x8* w = (const bf16x8*)packed;
   const int k = fwd_ksplit(B, Cin, H, W, Cout, stride);
   if (k > 1 && (!workspace || workspace_bytes < vg_conv5x5_fwd_bf16x3_workspace_bytes(B, Cin, H, W, Cout, stride)))
     return VG_ERR_WORKSPACE;
   g_xsplit = {k, (float*)workspace};
-  const int rc = (stride == 2) ? dispatch_x<X_FWD, 2>(x, w, bias, y, B, Cin, H, W, Cout, st)
-                               : dispatch_x<X_FWD, 1>(x, w, bias, y, B, Cin, H, W, Cout, st);
+  int rc;
+  if (planes == 2)
+    rc = (stride == 2) ? dispatch_x<X_FWD, 2, 2>(x, w, bias, y, B, Cin, H, W, Cout, st)
+                       : dispatch_x<X_FWD, 1, 2>(x, w, bias, y, B, Cin, H, W, Cout, st);
+  else
+    rc = (stride == 2) ? dispatch_x<X_FWD, 2, 3>(x, w, bias, y, B, Cin, H, W, Cout, st)
+                       : dispatch_x<X_FWD, 1, 3>(x, w, bias, y, B, Cin, H, W, Cout, st);
   g_xsplit = {1, nullptr};
   return rc;
 }
 
 extern "C" int vg_convT5x5_fwd_bf16x3(const float* x, const void* packed, const float* bias, float* y, int B, int Cin,
-                                      int H, int W, int Cout, int stride, void* stream) {
-  if (!x_args_ok(x, packed, y, B, Cin, H, W, Cout, stride)) return VG_ERR_BAD_ARG;
+                                      int H, int W, int Cout, int stride, int planes, void* stream) {
+  if (!x_args_ok(x, packed, y, B, Cin, H, W, Cout, stride, planes)) return VG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   const bf16x8* w = (const bf16x8*)packed;
-  if (stride == 2) return dispatch_x<X_TR, 2>(x, w, bias, y, B, Cin, H, W, Cout, st);
-  return dispatch_x<X_TR, 1>(x, w, bias, y, B, Cin, H, W, Cout, st);
+  if (planes == 2) {
+    if (stride == 2) return dispatch_x<X_TR, 2, 2>(x, w, bias, y, B, Cin, H, W, Cout, st);
+    return dispatch_x<X_TR, 1, 2>(x, w, bias, y, B, Cin, H, W, Cout, st);
+  }
+  if (stride == 2) return dispatch_x<X_TR, 2, 3>(x, w, bias, y, B, Cin, H, W, Cout, st);
+  return dispatch_x<X_TR, 1, 3>(x, w, bias, y, B, Cin, H, W, Cout, st);
 }

@@ -1,6 +1,6 @@
-// OPT-IN arithmetic mode of the 5x5 weight gradient (vg_conv5x5_wgrad_bf16x3) for gfx950, the
-// companion of conv_bf16x3.hip: hi/lo-split bf16 operands, lo*hi + hi*lo + hi*hi on
-// v_mfma_f32_32x32x16_bf16, fp32 accumulation (~4.5e-6 relative error; NOT the default).
+// OPT-IN arithmetic modes of the 5x5 weight gradient (vg_conv5x5_wgrad_bf16x3) for gfx950, the
+// companion of conv_bf16x3.hip: operands split into 2 (hi/lo, 3 products, ~4.5e-6) or 3 (hi/mid/lo,
+// 6 products, fp32-equivalent) bf16 planes, v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
 //
 //   dw[co][ci][kh][kw] = sum_{b,oh,ow} gy[b][co][oh][ow] * x[b][ci][S*oh+kh-2][S*ow+kw-2]
 //   (autograd of nn.Conv2d / nn.ConvTranspose2d, /root/reference/models/model.py:389-398, 450-456,
@@ -27,16 +27,18 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
-constexpr int WNT = 256, WTH = 4, WTW = 8, WCIT = 5, WTM = 128;
+constexpr int WNT = 256, WTW = 8, WCIT = 5, WTM = 128;
 
-template <int S_>
+// NP planes; the pixel tile of a chunk is WTH x 8 with WTH = 4 (2 planes) or 2 (3 planes: the patch is 1.5x
+// bigger per pixel and two workgroups must still share a CU's LDS)
+template <int S_, int NP_>
 struct WX {
-  static constexpr int S = S_;
+  static constexpr int S = S_, NP = NP_, WTH = (NP_ == 3) ? 2 : 4;
   static constexpr int PH = S * (WTH - 1) + 5, PW = S * (WTW - 1) + 5;
   static constexpr int ROWU = PW + ((5 - PW % 16) + 16) % 16;                    // = 5 (mod 16)
   static constexpr int CIU = PH * ROWU + ((9 - (PH * ROWU) % 16) + 16) % 16;     // = 9 (mod 16)
   static constexpr int KBU = WCIT * CIU;                                          // units per (plane, k-block)
-  static constexpr int NUNIT = 4 * WCIT * PH * PW;
+  static constexpr int NUNIT = 2 * NP * WCIT * PH * PW;
   static constexpr int NQ = cdiv(NUNIT, WNT);
 };
 
@@ -52,16 +54,22 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
+// v[8] -> NP bf16x8 values, each plane the leading 8 mantissa bits of what is left
+template <int NP>
+__device__ __forceinline__ void split_planes(float* v, bf16x8* out) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const __bf16 h = (__bf16)v[j];
-    hi[j] = h;
-    lo[j] = (__bf16)(v[j] - (float)h);
+  for (int p = 0; p < NP; ++p) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const __bf16 h = (__bf16)v[j];
+      out[p][j] = h;
+      v[j] -= (float)h;
+    }
   }
 }
 
 // ---- x[B][C][HW] -> Xp[bg][plane][kb][C][HW] x 8 images
+template <int NP>
 __global__ __launch_bounds__(256) void relayout_x_kernel(const float* __restrict__ x, bf16x8* __restrict__ xp, int B,
                                                         size_t chw) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -75,14 +83,15 @@ __global__ __launch_bounds__(256) void relayout_x_kernel(const float* __restrict
       const int b = bg * 16 + kb * 8 + j;
       v[j] = b < B ? x[(size_t)b * chw + e] : 0.f;
     }
-    bf16x8 hi, lo;
-    split8(v, hi, lo);
-    xp[((size_t)bg * 4 + kb) * chw + e] = hi;
-    xp[((size_t)bg * 4 + 2 + kb) * chw + e] = lo;
+    bf16x8 pl[NP];
+    split_planes<NP>(v, pl);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) xp[(((size_t)bg * NP + p) * 2 + kb) * chw + e] = pl[p];
   }
 }
 
 // ---- gy[B][Co][P] -> Gp[bg][p][plane][kb][CoP] x 8 images; 32 pixels x 32 channels per workgroup
+template <int NP>
 __global__ __launch_bounds__(256) void relayout_gy_kernel(const float* __restrict__ gy, bf16x8* __restrict__ gp,
                                                          int B, int Co, int CoP, int P) {
   __shared__ float tile[8][32][33];
@@ -112,18 +121,19 @@ __global__ __launch_bounds__(256) void relayout_gy_kernel(const float* __restric
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = tile[j][cc][pp];
-    bf16x8 hi, lo;
-    split8(v, hi, lo);
-    const size_t base = (((size_t)bg * P + p0 + pp) * 4 + kb) * CoP + co0 + cc;
-    gp[base] = hi;
-    gp[base + (size_t)2 * CoP] = lo;
+    bf16x8 pl[NP];
+    split_planes<NP>(v, pl);
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      gp[((((size_t)bg * P + p0 + pp) * NP + p) * 2 + kb) * CoP + co0 + cc] = pl[p];
   }
 }
 
 template <class C>
 __global__ __launch_bounds__(WNT, 2) void conv5x5_wgrad_bf16x3_kernel(WXArgs A) {
   constexpr int S = C::S, PH = C::PH, PW = C::PW, ROWU = C::ROWU, CIU = C::CIU, KBU = C::KBU, NQ = C::NQ;
-  __shared__ f32x4 lds[4 * KBU];      // [plane][k-block][ci][row][col] x 8 images
+  constexpr int NP = C::NP, WTH = C::WTH;
+  __shared__ f32x4 lds[2 * NP * KBU];      // [plane][k-block][ci][row][col] x 8 images
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int kb = lane >> 5, l32 = lane & 31;
   const int wm = wid & 1, wn = wid >> 1;
@@ -136,7 +146,7 @@ __global__ __launch_bounds__(WNT, 2) void conv5x5_wgrad_bf16x3_kernel(WXArgs A) 
   const int HW = H * W, P = A.OH * A.OW;
 
   // ---- staging map: unit e = (plane*2 + k-block, ci, row, col), one packed descriptor per unit
-  // (row | col << 4 | ci << 9 | pk << 12 | state << 14; state 0 = no unit, 1 = copy, 2 = channel
+  // (row | col << 4 | ci << 9 | pk << 12 | state << 15; state 0 = no unit, 1 = copy, 2 = channel
   // beyond Cin -> zeros); addresses are rebuilt from it per chunk to keep registers for the tile
   int desc[NQ];
 #pragma unroll
@@ -146,9 +156,9 @@ __global__ __launch_bounds__(WNT, 2) void conv5x5_wgrad_bf16x3_kernel(WXArgs A) 
     int t = e / PW;
     const int r = t % PH;
     t /= PH;
-    const int ci = t % WCIT, pk = min(t / WCIT, 3);
+    const int ci = t % WCIT, pk = min(t / WCIT, 2 * NP - 1);
     const int state = e < C::NUNIT ? ((ci0 + ci) < Cin ? 1 : 2) : 0;
-    desc[q] = r | (col << 4) | (ci << 9) | (pk << 12) | (state << 14);
+    desc[q] = r | (col << 4) | (ci << 9) | (pk << 12) | (state << 15);
   }
   static_assert(PH <= 16 && PW <= 32 && WCIT <= 8, "descriptor fields");
 
@@ -157,13 +167,13 @@ __global__ __launch_bounds__(WNT, 2) void conv5x5_wgrad_bf16x3_kernel(WXArgs A) 
   auto load_chunk = [&](int chunk) {
     const int bg = chunk / A.tiles_hw, sp = chunk % A.tiles_hw;
     const int ih0 = S * (sp / A.tiles_w) * WTH - 2, iw0 = S * (sp % A.tiles_w) * WTW - 2;
-    const f32x4* src = reinterpret_cast<const f32x4*>(A.xp) + (size_t)bg * 4 * Cin * HW;
+    const f32x4* src = reinterpret_cast<const f32x4*>(A.xp) + (size_t)bg * 2 * NP * Cin * HW;
     pvalid = 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int d = desc[q];
       const int ih = ih0 + (d & 15), iw = iw0 + ((d >> 4) & 31);
-      const int ci = (d >> 9) & 7, pk = (d >> 12) & 3;
+      const int ci = (d >> 9) & 7, pk = (d >> 12) & 7;
       const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
       pvalid |= ok ? (1u << q) : 0u;
       preg[q] = src[(pk * Cin + min(ci0 + ci, Cin - 1)) * HW + min(max(ih, 0), H - 1) * W + min(max(iw, 0), W - 1)];
@@ -173,8 +183,8 @@ __global__ __launch_bounds__(WNT, 2) void conv5x5_wgrad_bf16x3_kernel(WXArgs A) 
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int d = desc[q];
-      const int state = d >> 14;
-      const int dst = ((d >> 12) & 3) * KBU + ((d >> 9) & 7) * CIU + (d & 15) * ROWU + ((d >> 4) & 31);
+      const int state = d >> 15;
+      const int dst = ((d >> 12) & 7) * KBU + ((d >> 9) & 7) * CIU + (d & 15) * ROWU + ((d >> 4) & 31);
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
       if (state != 0) lds[dst] = (state == 1 && ((pvalid >> q) & 1u)) ? preg[q] : z;
     }
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(WNT, 2) void conv5x5_wgrad_bf16x3_kernel(WXArgs A) 
   const bf16x8* ga[2];
 #pragma unroll
   for (int g = 0; g < 2; ++g) ga[g] = A.gp + (size_t)kb * CoP + m0 + (wm * 2 + g) * 32 + l32;
-  const size_t gstep = (size_t)4 * CoP;     // units per pixel
+  const size_t gstep = (size_t)2 * NP * CoP;     // units per pixel
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -213,14 +223,13 @@ __global__ __launch_bounds__(WNT, 2) void conv5x5_wgrad_bf16x3_kernel(WXArgs A) 
       __syncthreads();
       const int bg = ch / A.tiles_hw, sp = ch % A.tiles_hw;
       const int th0 = (sp / A.tiles_w) * WTH, tw0 = (sp % A.tiles_w) * WTW;
-      bf16x8 a_hi[2][2], a_lo[2][2];
+      bf16x8 av[2][2][NP];      // [buffer][fragment][plane]
       {
         const size_t p = (size_t)bg * P + (size_t)th0 * OW + tw0;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          a_hi[0][g] = ga[g][p * gstep];
-          a_lo[0][g] = ga[g][p * gstep + 2 * CoP];
-        }
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int pl = 0; pl < NP; ++pl) av[0][g][pl] = ga[g][p * gstep + (size_t)pl * 2 * CoP];
       }
 #pragma unroll 1
       for (int ph = 0; ph < WTH; ++ph) {
@@ -232,28 +241,23 @@ __global__ __launch_bounds__(WNT, 2) void conv5x5_wgrad_bf16x3_kernel(WXArgs A) 
           const int cur = pw & 1, nxt = cur ^ 1;
           const size_t pn = (pw + 1 < WTW) ? prow + pw + 1 : pnext;
 #pragma unroll
-          for (int g = 0; g < 2; ++g) {
-            a_hi[nxt][g] = ga[g][pn * gstep];
-            a_lo[nxt][g] = ga[g][pn * gstep + 2 * CoP];
-          }
-          bf16x8 b_hi[2], b_lo[2];
-#pragma unroll
-          for (int f = 0; f < 2; ++f) {
-            b_hi[f] = __builtin_bit_cast(bf16x8, lds[base_b[f] + brow + S * pw]);
-            b_lo[f] = __builtin_bit_cast(bf16x8, lds[base_b[f] + brow + S * pw + 2 * KBU]);
-          }
-#pragma unroll
           for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int f = 0; f < 2; ++f) acc[g][f] = mfma_bf16(a_lo[cur][g], b_hi[f], acc[g][f]);
+            for (int pl = 0; pl < NP; ++pl) av[nxt][g][pl] = ga[g][pn * gstep + (size_t)pl * 2 * CoP];
+          bf16x8 bv[2][NP];
 #pragma unroll
-          for (int g = 0; g < 2; ++g)
+          for (int f = 0; f < 2; ++f)
 #pragma unroll
-            for (int f = 0; f < 2; ++f) acc[g][f] = mfma_bf16(a_hi[cur][g], b_lo[f], acc[g][f]);
+            for (int pl = 0; pl < NP; ++pl) bv[f][pl] = __builtin_bit_cast(bf16x8, lds[base_b[f] + brow + S * pw + pl * 2 * KBU]);
+          // products with plane index sum < NP, smallest terms first, product-major
 #pragma unroll
-          for (int g = 0; g < 2; ++g)
+          for (int sum = NP - 1; sum >= 0; --sum)
 #pragma unroll
-            for (int f = 0; f < 2; ++f) acc[g][f] = mfma_bf16(a_hi[cur][g], b_hi[f], acc[g][f]);
+            for (int pa = sum; pa >= 0; --pa)
+#pragma unroll
+              for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) acc[g][f] = mfma_bf16(av[cur][g][pa], bv[f][sum - pa], acc[g][f]);
         }
       }
       __syncthreads();
@@ -281,16 +285,17 @@ struct XPlan {
   size_t xp_bytes, gp_bytes, slab_bytes;
 };
 
-bool make_xplan(int B, int Cin, int H, int W, int Cout, int S, XPlan& p) {
+bool make_xplan(int B, int Cin, int H, int W, int Cout, int S, int planes, XPlan& p) {
+  const int wth = planes == 3 ? 2 : 4;
   p.OH = (H - 1) / S + 1;
   p.OW = (W - 1) / S + 1;
-  if (p.OH % WTH || p.OW % WTW) return false;          // whole 4 x 8 pixel tiles only (caller falls back to fp32)
+  if (p.OH % wth || p.OW % WTW) return false;          // whole pixel tiles only (caller falls back to fp32)
   p.BG = cdiv(B, 16);
   p.CoP = (Cout + 127) & ~127;
   p.mtiles = cdiv(Cout, WTM);
   p.ntiles = cdiv(Cin, WCIT);
   p.tiles_w = p.OW / WTW;
-  p.tiles_hw = p.tiles_w * (p.OH / WTH);
+  p.tiles_hw = p.tiles_w * (p.OH / wth);
   p.chunks = p.BG * p.tiles_hw;
   const int tiles = p.mtiles * p.ntiles;
   int want = cdiv(tiles >= 32 ? 2048 : 1024, tiles);
@@ -298,27 +303,37 @@ bool make_xplan(int B, int Cin, int H, int W, int Cout, int S, XPlan& p) {
   if (want < 1) want = 1;
   p.cps = cdiv(p.chunks, want);
   p.splits = cdiv(p.chunks, p.cps);
-  p.xp_bytes = (size_t)p.BG * 4 * Cin * H * W * 16;
-  p.gp_bytes = (size_t)p.BG * p.OH * p.OW * 4 * p.CoP * 16;
+  p.xp_bytes = (size_t)p.BG * 2 * planes * Cin * H * W * 16;
+  p.gp_bytes = (size_t)p.BG * p.OH * p.OW * 2 * planes * p.CoP * 16;
   p.slab_bytes = (size_t)p.splits * Cout * Cin * 25 * sizeof(float);
   return true;
 }
 
+template <class C>
+int launch_wx(const WXArgs& A, long grid, hipStream_t st) {
+  hipLaunchKernelGGL(conv5x5_wgrad_bf16x3_kernel<C>, dim3((unsigned)grid), dim3(WNT), 0, st, A);
+  VG_CHECK_LAUNCH();
+  return 0;
+}
+
 }  // namespace
 
-extern "C" size_t vg_conv5x5_wgrad_bf16x3_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride) {
+extern "C" size_t vg_conv5x5_wgrad_bf16x3_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride,
+                                                          int planes) {
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return 0;
+  if (planes != 2 && planes != 3) return 0;
   XPlan p;
-  if (!make_xplan(B, Cin, H, W, Cout, stride, p)) return 0;     // 0: shape not supported by this mode
+  if (!make_xplan(B, Cin, H, W, Cout, stride, planes, p)) return 0;     // 0: shape not supported by this mode
   return p.xp_bytes + p.gp_bytes + p.slab_bytes;
 }
 
 extern "C" int vg_conv5x5_wgrad_bf16x3(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W,
-                                       int Cout, int stride, void* workspace, size_t workspace_bytes, void* stream) {
+                                       int Cout, int stride, int planes, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
   if (!x || !gy || !dw || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return VG_ERR_BAD_ARG;
-  if (stride != 1 && stride != 2) return VG_ERR_BAD_ARG;
+  if ((stride != 1 && stride != 2) || (planes != 2 && planes != 3)) return VG_ERR_BAD_ARG;
   XPlan p;
-  if (!make_xplan(B, Cin, H, W, Cout, stride, p)) return VG_ERR_BAD_ARG;
+  if (!make_xplan(B, Cin, H, W, Cout, stride, planes, p)) return VG_ERR_BAD_ARG;
   if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < p.xp_bytes + p.gp_bytes + p.slab_bytes)
     return VG_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -327,11 +342,15 @@ extern "C" int vg_conv5x5_wgrad_bf16x3(const float* x, const float* gy, float* d
   float* slabs = (float*)((char*)workspace + p.xp_bytes + p.gp_bytes);
   const size_t chw = (size_t)Cin * H * W;
   const int P = p.OH * p.OW;
-  if (cdiv((long)chw, 256L) > 0x7fffffffL || p.BG > 65535 || p.BG * 2 > 65535 || p.CoP / 32 > 65535) return VG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(relayout_x_kernel, dim3((unsigned)((chw + 255) / 256), p.BG), dim3(256), 0, st, x, xp, B, chw);
-  VG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(relayout_gy_kernel, dim3(cdiv(P, 32), p.CoP / 32, p.BG * 2), dim3(256), 0, st, gy, gp, B, Cout,
-                     p.CoP, P);
+  if (cdiv((long)chw, 256L) > 0x7fffffffL || p.BG * 2 > 65535 || p.CoP / 32 > 65535) return VG_ERR_BAD_ARG;
+  const dim3 gx((unsigned)((chw + 255) / 256), p.BG), gg(cdiv(P, 32), p.CoP / 32, p.BG * 2);
+  if (planes == 2) {
+    hipLaunchKernelGGL(relayout_x_kernel<2>, gx, dim3(256), 0, st, x, xp, B, chw);
+    hipLaunchKernelGGL(relayout_gy_kernel<2>, gg, dim3(256), 0, st, gy, gp, B, Cout, p.CoP, P);
+  } else {
+    hipLaunchKernelGGL(relayout_x_kernel<3>, gx, dim3(256), 0, st, x, xp, B, chw);
+    hipLaunchKernelGGL(relayout_gy_kernel<3>, gg, dim3(256), 0, st, gy, gp, B, Cout, p.CoP, P);
+  }
   VG_CHECK_LAUNCH();
   WXArgs A;
   A.xp = xp; A.gp = gp; A.ws = slabs;
@@ -340,10 +359,9 @@ extern "C" int vg_conv5x5_wgrad_bf16x3(const float* x, const float* gy, float* d
   A.chunks = p.chunks; A.chunks_per_split = p.cps;
   const long grid = (long)p.mtiles * p.ntiles * p.splits;
   if (grid > 0x7fffffffL) return VG_ERR_BAD_ARG;
-  if (stride == 2)
-    hipLaunchKernelGGL(conv5x5_wgrad_bf16x3_kernel<WX<2>>, dim3((unsigned)grid), dim3(WNT), 0, st, A);
-  else
-    hipLaunchKernelGGL(conv5x5_wgrad_bf16x3_kernel<WX<1>>, dim3((unsigned)grid), dim3(WNT), 0, st, A);
-  VG_CHECK_LAUNCH();
+  int rc;
+  if (planes == 2) rc = (stride == 2) ? launch_wx<WX<2, 2>>(A, grid, st) : launch_wx<WX<1, 2>>(A, grid, st);
+  else rc = (stride == 2) ? launch_wx<WX<2, 3>>(A, grid, st) : launch_wx<WX<1, 3>>(A, grid, st);
+  if (rc) return rc;
   return vg_internal_wgrad_reduce(slabs, dw, Cout * Cin * 25, p.splits, st);
 }

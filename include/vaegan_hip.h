@@ -82,30 +82,35 @@ int vg_conv5x5_fwd_packed(const float* x, const float* packed, const float* bias
 int vg_convT5x5_fwd_packed(const float* x, const float* packed, const float* bias, float* y,
                            int B, int Cin, int H, int W, int Cout, int stride, void* stream);
 
-/* OPT-IN arithmetic mode of vg_conv5x5_fwd / vg_convT5x5_fwd (not used by default; DESIGN.md
- * section 8): operands split into bf16 hi/lo pairs, lo*hi + hi*lo + hi*hi on the bf16 MFMA with fp32
- * accumulation -- ~4.5e-6 relative error against fp64 where the exact-fp32 path has 5e-7..1e-6.
- * Requires Cin % 16 == 0.  `packed` holds vg_conv5x5_packed_bf16x3_bytes(Cout, Cin) bytes (16-byte
- * aligned), written by vg_conv5x5_pack_bf16x3 once per weight version:
+/* OPT-IN arithmetic modes of vg_conv5x5_fwd / vg_convT5x5_fwd (not used by default; DESIGN.md
+ * section 8): every fp32 operand is split into `planes` bf16 values and the products whose plane indices
+ * sum to < planes are evaluated on the bf16 MFMA with fp32 accumulation:
+ *   planes = 2  hi/lo, 3 MFMAs per product ("bf16x3"): ~4.5e-6 relative error against fp64
+ *               (the exact-fp32 kernels: 5e-7..1e-6);
+ *   planes = 3  hi/mid/lo = the whole 24-bit mantissa, 6 MFMAs per product ("bf16x6"): every dropped
+ *               term is below 2^-24 -- fp32-equivalent.
+ * Requires Cin % 16 == 0.  `packed` holds vg_conv5x5_packed_bf16x3_bytes(Cout, Cin, planes) bytes
+ * (16-byte aligned), written by vg_conv5x5_pack_bf16x3 once per weight version:
  *   transposed = 0: from w[Cout,Cin,5,5] for vg_conv5x5_fwd_bf16x3 (stride ignored);
  *   transposed = 1: from w[Cin,Cout,5,5] for vg_convT5x5_fwd_bf16x3 with the SAME stride. */
-int vg_debug_set_conv_bf16x3_tile(int variant);   /* tuning only: 0 = 128x128, 1 = 64x128, 2 = 64x64, 3 = 32x128, -1 = heuristic */
-size_t vg_conv5x5_packed_bf16x3_bytes(int Cout, int Cin);
+int vg_debug_set_conv_bf16x3_tile(int variant);   /* tuning only: 0 = 128x128, 1 = 64x128, 2 = 64x64, 3 = 32x128, 4 = 32x256 (transposed), -1 = heuristic */
+size_t vg_conv5x5_packed_bf16x3_bytes(int Cout, int Cin, int planes);
 int vg_conv5x5_pack_bf16x3(const float* w, void* packed, int Cout, int Cin, int transposed, int stride,
-                           void* stream);
+                           int planes, void* stream);
 size_t vg_conv5x5_fwd_bf16x3_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride);   /* 0 for most shapes */
 int vg_conv5x5_fwd_bf16x3(const float* x, const void* packed, const float* bias, float* y,
-                          int B, int Cin, int H, int W, int Cout, int stride,
+                          int B, int Cin, int H, int W, int Cout, int stride, int planes,
                           void* workspace, size_t workspace_bytes, void* stream);
 int vg_convT5x5_fwd_bf16x3(const float* x, const void* packed, const float* bias, float* y,
-                           int B, int Cin, int H, int W, int Cout, int stride, void* stream);
+                           int B, int Cin, int H, int W, int Cout, int stride, int planes, void* stream);
 /* vg_conv5x5_wgrad in the same opt-in arithmetic.  The reduction runs over images in groups of 16
  * (operands re-laid batch-innermost inside the call; B is zero-padded to a multiple of 16); needs
- * OH % 4 == 0 and OW % 8 == 0 -- the workspace query returns 0 for shapes it does not take
+ * OH % 4 == 0 (planes = 2) or OH % 2 == 0 (planes = 3) and OW % 8 == 0 -- the workspace query returns 0 for shapes it does not take
  * (use vg_conv5x5_wgrad).  workspace: 16-byte aligned. */
-size_t vg_conv5x5_wgrad_bf16x3_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride);
+size_t vg_conv5x5_wgrad_bf16x3_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride, int planes);
 int vg_conv5x5_wgrad_bf16x3(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W,
-                            int Cout, int stride, void* workspace, size_t workspace_bytes, void* stream);
+                            int Cout, int stride, int planes, void* workspace, size_t workspace_bytes,
+                            void* stream);
 
 /* dw[Cout,Cin,5,5] = sum_{b,oh,ow} gy[b,co,oh,ow] * x[b,ci,s*oh+kh-2,s*ow+kw-2].
  * Weight gradient of nn.Conv2d (autograd of model.py:450...; new_betavaegan.py:103,121)

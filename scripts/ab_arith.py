@@ -11,21 +11,22 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 x = (torch.rand(B, 3, 64, 64) * 2 - 1).cuda()
 n = [torch.randn(B, 128).cuda() for _ in range(3)]
 first = {}
-for mode in ("fp32", "bf16x3"):
+MODES = ("fp32", "bf16x6", "bf16x3")
+for mode in MODES:
     ops.CONV_FWD_ARITH = mode
     tr = BetaVAEGANTrainer(beta=25.0)
     out = tr.step(x, *n)
     first[mode] = {k: float(v) for k, v in out.items()}
 ops.CONV_FWD_ARITH = "fp32"
 for k in first["fp32"]:
-    a, b = first["fp32"][k], first["bf16x3"][k]
-    print(f"{k:12s} fp32 {a:14.6f}  bf16x3 {b:14.6f}  rel {abs(a-b)/max(abs(a),1e-30):.2e}")
+    a = first["fp32"][k]
+    print(f"{k:12s} fp32 {a:14.6f}  " + "  ".join(f"{m} rel {abs(a-first[m][k])/max(abs(a),1e-30):.2e}" for m in MODES[1:]))
 tr = BetaVAEGANTrainer(beta=25.0)
 for _ in range(5):
     tr.step(x)
-res = {"fp32": [], "bf16x3": []}
+res = {m: [] for m in MODES}
 for rnd in range(4):
-    for mode in ("fp32", "bf16x3"):
+    for mode in MODES:
         ops.CONV_FWD_ARITH = mode
         tr.step(x)
         torch.cuda.synchronize()

@@ -13,8 +13,9 @@ from oracle import ops as O
 pytestmark = pytest.mark.gpu
 
 # Convolution tolerance (relative L2 against the fp64 oracle): 3e-6 for the default exact-fp32 kernels;
-# 2e-5 when the suite is run with VG_CONV_ARITH=bf16x3 exported (the opt-in split-bf16 arithmetic).
-CONV_TOL = 3e-6 if os.environ.get("VG_CONV_ARITH", "fp32") == "fp32" else 2e-5
+# 2e-5 when the suite is run with VG_CONV_ARITH=bf16x3 exported (the opt-in 2-plane split-bf16 arithmetic);
+# VG_CONV_ARITH=bf16x6 (3 planes, the whole fp32 mantissa) is held to the fp32 tolerance.
+CONV_TOL = 2e-5 if os.environ.get("VG_CONV_ARITH", "fp32") == "bf16x3" else 3e-6      # fp32 and bf16x6: fp32-level
 
 
 @pytest.fixture(scope="module")
@@ -519,8 +520,10 @@ def test_conv_wgrad_bf16x3(H, B, Cin, Cout, Hs, Ws, stride):
 def test_conv_wgrad_bf16x3_unsupported_shape_falls_back(H):
     from disentangle_mlp_amd import _lib
     lib = _lib.load()
-    assert lib.vg_conv5x5_wgrad_bf16x3_workspace_bytes(4, 8, 10, 10, 8, 2) == 0     # 5 x 5 outputs
-    assert lib.vg_conv5x5_wgrad_bf16x3_workspace_bytes(4, 8, 16, 16, 8, 2) > 0
+    assert lib.vg_conv5x5_wgrad_bf16x3_workspace_bytes(4, 8, 10, 10, 8, 2, 2) == 0     # 5 x 5 outputs
+    assert lib.vg_conv5x5_wgrad_bf16x3_workspace_bytes(4, 8, 16, 16, 8, 2, 2) > 0
+    assert lib.vg_conv5x5_wgrad_bf16x3_workspace_bytes(4, 8, 12, 16, 8, 2, 3) > 0      # 6 x 8 outputs: 3 planes tile 2 x 8
+    assert lib.vg_conv5x5_wgrad_bf16x3_workspace_bytes(4, 8, 12, 16, 8, 2, 2) == 0
     x, gy = _rand(2, 3, 10, 10, seed=3), _rand(2, 4, 5, 5, seed=4)
     w = 0.1 * _rand(4, 3, 5, 5, seed=5)
     prev_arith = H.CONV_FWD_ARITH
@@ -551,3 +554,32 @@ def test_conv_fwd_bf16x3_split_k(H):
             H.CONV_FWD_ARITH = prev_arith
         assert_close(y, O.conv5x5(x, w, bias, s), 2e-5, f"split-K {B} {Cin} {Cout}")
     assert lib.vg_conv5x5_fwd_bf16x3_workspace_bytes(128, 128, 32, 32, 256, 2) == 0      # large grid: no split
+
+
+# ------------------------------------------------------------------ opt-in bf16x6 (fp32-equivalent) mode
+@pytest.mark.parametrize("B,Cin,Cout,Hs,Ws,stride", [
+    (3, 16, 32, 16, 16, 2), (2, 128, 256, 32, 32, 2), (5, 48, 70, 13, 9, 2), (3, 16, 130, 16, 24, 1),
+    (16, 256, 256, 16, 16, 2), (20, 32, 128, 16, 32, 2)])
+def test_bf16x6_is_fp32_equivalent(H, B, Cin, Cout, Hs, Ws, stride):
+    """ops.CONV_FWD_ARITH = "bf16x6": operands split into three bf16 planes (8 + 8 + 8 mantissa bits, exact),
+    6 products per multiply, fp32 accumulation.  Held to the SAME 3e-6 as the exact-fp32 kernels, for the
+    forward, transposed (= data gradient) and weight-gradient kernels."""
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(B, Cin, Hs, Ws, generator=g)
+    w = torch.randn(Cout, Cin, 5, 5, generator=g) * 0.05
+    wt = torch.randn(Cin, Cout, 5, 5, generator=g) * 0.05
+    bias = torch.randn(Cout, generator=g)
+    y_ref = O.conv5x5(x, w, bias, stride)
+    gy = torch.randn(*y_ref.shape, generator=g)
+    gx_ref, gw_ref = O.conv5x5_grads(x, w, gy, stride)
+    prev_arith = H.CONV_FWD_ARITH
+    try:
+        H.CONV_FWD_ARITH = "bf16x6"
+        assert_close(H.conv5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), stride), y_ref, 3e-6, "bf16x6 fwd")
+        assert_close(H.convT5x5_fwd(x.cuda(), wt.cuda(), bias.cuda(), stride), O.convT5x5(x, wt, bias, stride), 3e-6,
+                     "bf16x6 convT")
+        if (Hs * stride) % stride == 0 and gx_ref.shape[2] == gy.shape[2] * stride and gx_ref.shape[3] == gy.shape[3] * stride:
+            assert_close(H.convT5x5_fwd(gy.cuda(), w.cuda(), None, stride), gx_ref, 3e-6, "bf16x6 dgrad")
+        assert_close(H.conv5x5_wgrad(x.cuda(), gy.cuda(), stride), gw_ref, 3e-6, "bf16x6 wgrad")
+    finally:
+        H.CONV_FWD_ARITH = prev_arith
