@@ -98,10 +98,10 @@ def test_betavaegan_step_vs_golden(T, batch):
     assert int(tr.netEG.state_dict()["act1.0.num_batches_tracked"]) == 3
 
 
-@pytest.mark.parametrize("arith,loss_tol,grad_tol", [("fp32", 2e-5, 3e-3), ("bf16x3", 1e-4, 1e-2)])
+@pytest.mark.parametrize("arith,loss_tol,grad_tol", [("fp32", 2e-5, 3e-3), ("bf16x6", 2e-5, 3e-3), ("bf16x3", 1e-4, 1e-2)])
 def test_betavaegan_gradients_vs_live_oracle(T, arith, loss_tol, grad_tol):
-    """(Also run in the OPT-IN bf16x3 arithmetic of the forward / data-gradient convolutions: 4.5e-6
-    per convolution instead of 5e-7, so losses are held to 1e-4 and gradients to 1e-2 there.)
+    """(Also run in the OPT-IN split-bf16 arithmetics: bf16x6 -- the exact 3-plane split -- at the fp32
+    tolerances; bf16x3 -- 4.5e-6 per convolution instead of 5e-7 -- at 1e-4 for losses and 1e-2 for gradients.)
     Per-parameter gradients of all three phases vs the oracle (fp64, host CPU), B=8, with
     lr = 0 so that every phase differentiates at the same (initial) weights: this isolates the
     kernels from the chaotic sensitivity of Adam's first sign-like update.  Tolerance 3e-3
@@ -143,7 +143,7 @@ def test_betavaegan_gradients_vs_live_oracle(T, arith, loss_tol, grad_tol):
         for (k, v), (_, r) in zip(net.state_dict().items(), ref.state_dict().items()):
             if "running" in k:
                 e = float((v.cpu().double() - r).norm() / max(float(r.norm()), 1e-30))
-                assert e <= (2e-5 if arith == "fp32" else 1e-4), (k, e)
+                assert e <= (1e-4 if arith == "bf16x3" else 2e-5), (k, e)
             if "num_batches" in k:
                 assert int(v) == int(r), k
 
