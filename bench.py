@@ -110,7 +110,7 @@ def main():
     from disentangle_mlp_amd.trainer import BetaVAEGANTrainer
 
     B = args.batch
-    arith = ops.CONV_FWD_ARITH               # "fp32" unless VG_CONV_ARITH=bf16x3 was exported
+    arith = ops.CONV_ARITH               # "fp32" unless VG_CONV_ARITH=bf16x3 was exported
     tr = BetaVAEGANTrainer(device=dev, seed=999, beta=args.beta)
     g = torch.Generator().manual_seed(1234 + rank)            # each rank its own shard
     data = (torch.rand(B, 3, 64, 64, generator=g) * 2 - 1).to(dev)
@@ -159,7 +159,7 @@ def main():
                             "tests hold it to 2e-5 per convolution", 4.5e-6)}
         try:
             for mode in ("bf16x6", "bf16x3"):
-                ops.CONV_FWD_ARITH = mode
+                ops.CONV_ARITH = mode
                 for _ in range(2):
                     one_step()
                 torch.cuda.synchronize()
@@ -173,8 +173,8 @@ def main():
                                 "arithmetic": notes[mode][0], "conv_rel_error_vs_fp64": notes[mode][1],
                                 "losses_finite": all(bool(torch.isfinite(v).all()) for v in out2.values())}
         finally:
-            ops.CONV_FWD_ARITH = "fp32"
-        opt_in["note"] = ("ops.CONV_FWD_ARITH / VG_CONV_ARITH; not the headline: `value` is the exact-fp32-MFMA path "
+            ops.CONV_ARITH = "fp32"
+        opt_in["note"] = ("ops.CONV_ARITH / VG_CONV_ARITH; not the headline: `value` is the exact-fp32-MFMA path "
                           "(conv rel. error vs fp64 5e-7..1e-6)")
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -197,7 +197,7 @@ def main():
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": None if x3 else traffic, "traffic_unit": "bytes/launch",
                     "traffic_source": None if x3 else tsrc,
-                    "kernel": ("conv5x5_bf16x3_kernel (%d bf16 MFMAs per product: effective peak %.0f)" % (nprod, peak / nprod)) if x3
+                    "kernel": ("conv5x5_bf16split_kernel (%d bf16 MFMAs per product: effective peak %.0f)" % (nprod, peak / nprod)) if x3
                     else ("conv5x5_igemm_kernel" if dominant[0] != "conv_wgrad" else "conv5x5_wgrad_kernel"),
                     "launch": {"op": dominant[0], "B": dominant[1], "Cin": dominant[2], "H": dominant[3],
                                "W": dominant[4], "Cout": dominant[5], "stride": dominant[6]},

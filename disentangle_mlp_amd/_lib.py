@@ -28,14 +28,14 @@ SIGNATURES = {
     "vg_conv5x5_pack": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "vg_conv5x5_fwd_packed": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_convT5x5_fwd_packed": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "vg_debug_set_conv_bf16x3_tile": (_I, [_I]),
-    "vg_conv5x5_packed_bf16x3_bytes": (_Z, [_I, _I, _I]),
-    "vg_conv5x5_pack_bf16x3": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "vg_convT5x5_fwd_bf16x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "vg_conv5x5_fwd_bf16x3_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
-    "vg_conv5x5_fwd_bf16x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
-    "vg_conv5x5_wgrad_bf16x3_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
-    "vg_conv5x5_wgrad_bf16x3": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "vg_debug_set_conv_bf16split_tile": (_I, [_I]),
+    "vg_conv5x5_packed_bf16split_bytes": (_Z, [_I, _I, _I]),
+    "vg_conv5x5_pack_bf16split": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "vg_convT5x5_fwd_bf16split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "vg_conv5x5_fwd_bf16split_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "vg_conv5x5_fwd_bf16split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "vg_conv5x5_wgrad_bf16split_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
+    "vg_conv5x5_wgrad_bf16split": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "vg_conv5x5_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "vg_conv5x5_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "vg_channel_sum": (_I, [_P, _P, _I, _I, _I, _P, _Z, _P]),

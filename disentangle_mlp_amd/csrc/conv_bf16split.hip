@@ -1,5 +1,5 @@
 // OPT-IN arithmetic mode of the 5x5 convolution / transposed convolution forward kernels
-// (vg_conv5x5_fwd_bf16x3, vg_convT5x5_fwd_bf16x3) for gfx950: every fp32 operand is split into two
+// (vg_conv5x5_fwd_bf16split, vg_convT5x5_fwd_bf16split) for gfx950: every fp32 operand is split into two
 // bf16 values (hi = bf16(x), lo = bf16(x - hi)) and each product is evaluated as
 // lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- 3 bf16 MFMAs per
 // 16 k in 96 cycles where the exact-fp32 MFMA needs 8 x 64.  Measured error against fp64:
@@ -18,7 +18,7 @@
 //     kept apart so that the 32 pixels of a fragment read consecutive 16-byte units; row strides are
 //     chosen so that the rows a fragment spans fall on disjoint banks.  The fp32 -> hi/lo split
 //     happens once per element, when the prefetched registers are written to LDS.
-//   * The filter never touches LDS: it comes pre-split and pre-packed (vg_conv5x5_pack_bf16x3) as
+//   * The filter never touches LDS: it comes pre-split and pre-packed (vg_conv5x5_pack_bf16split) as
 //     [parity class][chunk][tap][plane][k-block][cout] x 8 bf16, so a lane's A operand is one 16-byte
 //     global load (32 consecutive cout = 512 contiguous bytes), prefetched one tap ahead.
 //   * The stride-2 transposed convolution runs as its 4 output-parity classes (3x3, 3x2, 2x3, 2x2
@@ -96,7 +96,7 @@ __host__ __device__ constexpr int x_taps_before(int S, int R, int SS) {
 }
 
 template <class C, int R, int SS>
-__device__ __forceinline__ void bf16x3_body(const XArgs& A, f32x4* lds, int bid, int split) {
+__device__ __forceinline__ void bf16split_body(const XArgs& A, f32x4* lds, int bid, int split) {
   constexpr int MODE = C::MODE, S = C::S, NB = C::NB, TH = C::TH, TW = C::TW, PH = C::PH, PW = C::PW;
   constexpr int COLS = C::COLS, ROWU = C::ROWU, IMGU = C::IMGU, NQ = C::NQ, FC = C::FC, FP = C::FP, NP = C::NP;
   constexpr int NTMAX = C::NTMAX;
@@ -294,20 +294,20 @@ __device__ __forceinline__ void bf16x3_body(const XArgs& A, f32x4* lds, int bid,
 }
 
 template <class C>
-__global__ __launch_bounds__(XNT, 2) void conv5x5_bf16x3_kernel(XArgs A) {
+__global__ __launch_bounds__(XNT, 2) void conv5x5_bf16split_kernel(XArgs A) {
   __shared__ f32x4 lds[2 * C::NP * C::IMGU];     // [plane][k-block][image][row][(parity)][column]
   int bid = blockIdx.x;
   if constexpr (C::NCLS == 1) {
     const int split = bid / A.blocks_per_cls;
-    bf16x3_body<C, 0, 0>(A, lds, bid - split * A.blocks_per_cls, split);
+    bf16split_body<C, 0, 0>(A, lds, bid - split * A.blocks_per_cls, split);
   } else {
     const int cls = bid / A.blocks_per_cls;   // class 0 (3x3 taps) first: longest blocks start earliest
     bid -= cls * A.blocks_per_cls;
     switch (cls) {
-      case 0: bf16x3_body<C, 0, 0>(A, lds, bid, 0); break;
-      case 1: bf16x3_body<C, 0, 1>(A, lds, bid, 0); break;
-      case 2: bf16x3_body<C, 1, 0>(A, lds, bid, 0); break;
-      default: bf16x3_body<C, 1, 1>(A, lds, bid, 0); break;
+      case 0: bf16split_body<C, 0, 0>(A, lds, bid, 0); break;
+      case 1: bf16split_body<C, 0, 1>(A, lds, bid, 0); break;
+      case 2: bf16split_body<C, 1, 0>(A, lds, bid, 0); break;
+      default: bf16split_body<C, 1, 1>(A, lds, bid, 0); break;
     }
   }
 }
@@ -344,7 +344,7 @@ int launch_x(const float* x, const bf16x8* w, const float* bias, float* y, int B
   A.cps = cdiv(Cin / 16, ksplit);
   A.ysplit = (size_t)B * Cout * A.YH * A.YW;
   if (ksplit > 1) A.y = g_xsplit.slabs;
-  hipLaunchKernelGGL(conv5x5_bf16x3_kernel<C>, dim3((unsigned)grid), dim3(XNT), 0, st, A);
+  hipLaunchKernelGGL(conv5x5_bf16split_kernel<C>, dim3((unsigned)grid), dim3(XNT), 0, st, A);
   VG_CHECK_LAUNCH();
   if (ksplit > 1) {
     if (A.ysplit > 0x7fffffffUL) return VG_ERR_BAD_ARG;
@@ -403,7 +403,7 @@ int dispatch_x(const float* x, const bf16x8* w, const float* bias, float* y, int
 //   transposed = 0: w is [Cout][Cin][5][5], one class of 25 taps (kh*5 + kw);
 //   transposed = 1: w is [Cin][Cout][5][5], S*S parity classes, tap (a, b) of class (R, SS) is
 //                   (kh, kw) = (R + S*a, SS + S*b).
-__global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float* __restrict__ w, bf16x8* __restrict__ p,
+__global__ __launch_bounds__(256) void pack_bf16split_kernel(const float* __restrict__ w, bf16x8* __restrict__ p,
                                                          int Cout, int Cin, int CoutP, int nsteps, int transposed,
                                                          int S, int planes) {
   const int co = blockIdx.x * 256 + threadIdx.x;
@@ -476,42 +476,42 @@ int x_args_ok(const float* x, const void* packed, float* y, int B, int Cin, int 
 
 }  // namespace
 
-extern "C" int vg_debug_set_conv_bf16x3_tile(int variant) {
+extern "C" int vg_debug_set_conv_bf16split_tile(int variant) {
   g_x_tile_override = variant;
   return 0;
 }
 
-extern "C" size_t vg_conv5x5_packed_bf16x3_bytes(int Cout, int Cin, int planes) {
+extern "C" size_t vg_conv5x5_packed_bf16split_bytes(int Cout, int Cin, int planes) {
   if (Cout <= 0 || Cin <= 0 || Cin % 16 || (planes != 2 && planes != 3)) return 0;
   return (size_t)(Cin / 16 * 25 + 1) * 2 * planes * ((Cout + 127) & ~127) * 16;
 }
 
-extern "C" int vg_conv5x5_pack_bf16x3(const float* w, void* packed, int Cout, int Cin, int transposed, int stride,
+extern "C" int vg_conv5x5_pack_bf16split(const float* w, void* packed, int Cout, int Cin, int transposed, int stride,
                                       int planes, void* stream) {
   if (!w || !packed || Cout <= 0 || Cin <= 0 || Cin % 16 || ((uintptr_t)packed & 15)) return VG_ERR_BAD_ARG;
   if ((stride != 1 && stride != 2) || (planes != 2 && planes != 3)) return VG_ERR_BAD_ARG;
   const int CoutP = (Cout + 127) & ~127, nsteps = Cin / 16 * 25;
-  hipLaunchKernelGGL(pack_bf16x3_kernel, dim3(cdiv(CoutP, 256), nsteps + 1), dim3(256), 0, (hipStream_t)stream, w,
+  hipLaunchKernelGGL(pack_bf16split_kernel, dim3(cdiv(CoutP, 256), nsteps + 1), dim3(256), 0, (hipStream_t)stream, w,
                      (bf16x8*)packed, Cout, Cin, CoutP, nsteps, transposed ? 1 : 0, transposed ? stride : 1, planes);
   VG_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" size_t vg_conv5x5_fwd_bf16x3_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride) {
+extern "C" size_t vg_conv5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride) {
   if (B <= 0 || Cin <= 0 || Cin % 16 || Cout <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return 0;
   const int k = fwd_ksplit(B, Cin, H, W, Cout, stride);
   if (k <= 1) return 0;
   return (size_t)k * B * Cout * ((H - 1) / stride + 1) * ((W - 1) / stride + 1) * sizeof(float);
 }
 
-extern "C" int vg_conv5x5_fwd_bf16x3(const float* x, const void* packed, const float* bias, float* y, int B, int Cin,
+extern "C" int vg_conv5x5_fwd_bf16split(const float* x, const void* packed, const float* bias, float* y, int B, int Cin,
                                      int H, int W, int Cout, int stride, int planes, void* workspace,
                                      size_t workspace_bytes, void* stream) {
   if (!x_args_ok(x, packed, y, B, Cin, H, W, Cout, stride, planes)) return VG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   const bf16x8* w = (const bf16x8*)packed;
   const int k = fwd_ksplit(B, Cin, H, W, Cout, stride);
-  if (k > 1 && (!workspace || workspace_bytes < vg_conv5x5_fwd_bf16x3_workspace_bytes(B, Cin, H, W, Cout, stride)))
+  if (k > 1 && (!workspace || workspace_bytes < vg_conv5x5_fwd_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride)))
     return VG_ERR_WORKSPACE;
   g_xsplit = {k, (float*)workspace};
   int rc;
@@ -525,7 +525,7 @@ extern "C" int vg_conv5x5_fwd_bf16x3(const float* x, const void* packed, const f
   return rc;
 }
 
-extern "C" int vg_convT5x5_fwd_bf16x3(const float* x, const void* packed, const float* bias, float* y, int B, int Cin,
+extern "C" int vg_convT5x5_fwd_bf16split(const float* x, const void* packed, const float* bias, float* y, int B, int Cin,
                                       int H, int W, int Cout, int stride, int planes, void* stream) {
   if (!x_args_ok(x, packed, y, B, Cin, H, W, Cout, stride, planes)) return VG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;

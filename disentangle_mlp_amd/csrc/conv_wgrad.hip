@@ -326,7 +326,7 @@ int dispatch_tw(const WArgs& A, int tw, int tm, int cit, hipStream_t st) {
 
 }  // namespace
 
-// shared with wgrad_bf16x3.hip: dw[i] = sum over `splits` slabs of n floats, fixed order
+// shared with wgrad_bf16split.hip: dw[i] = sum over `splits` slabs of n floats, fixed order
 int vg_internal_wgrad_reduce(const float* slabs, float* dw, int n, int splits, hipStream_t st) {
   if (splits >= 64 && cdiv(n, 64) < 1024)
     hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(cdiv(n, 64)), dim3(1024), 0, st, slabs, dw, n, splits);

@@ -1,5 +1,5 @@
-// OPT-IN arithmetic modes of the 5x5 weight gradient (vg_conv5x5_wgrad_bf16x3) for gfx950, the
-// companion of conv_bf16x3.hip: operands split into 2 (hi/lo, 3 products, ~4.5e-6) or 3 (hi/mid/lo,
+// OPT-IN arithmetic modes of the 5x5 weight gradient (vg_conv5x5_wgrad_bf16split) for gfx950, the
+// companion of conv_bf16split.hip: operands split into 2 (hi/lo, 3 products, ~4.5e-6) or 3 (hi/mid/lo,
 // 6 products, fp32-equivalent) bf16 planes, v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
 //
 //   dw[co][ci][kh][kw] = sum_{b,oh,ow} gy[b][co][oh][ow] * x[b][ci][S*oh+kh-2][S*ow+kw-2]
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void relayout_gy_kernel(const float* __restric
 }
 
 template <class C>
-__global__ __launch_bounds__(WNT, 2) void conv5x5_wgrad_bf16x3_kernel(WXArgs A) {
+__global__ __launch_bounds__(WNT, 2) void conv5x5_wgrad_bf16split_kernel(WXArgs A) {
   constexpr int S = C::S, PH = C::PH, PW = C::PW, ROWU = C::ROWU, CIU = C::CIU, KBU = C::KBU, NQ = C::NQ;
   constexpr int NP = C::NP, WTH = C::WTH;
   __shared__ f32x4 lds[2 * NP * KBU];      // [plane][k-block][ci][row][col] x 8 images
@@ -311,14 +311,14 @@ bool make_xplan(int B, int Cin, int H, int W, int Cout, int S, int planes, XPlan
 
 template <class C>
 int launch_wx(const WXArgs& A, long grid, hipStream_t st) {
-  hipLaunchKernelGGL(conv5x5_wgrad_bf16x3_kernel<C>, dim3((unsigned)grid), dim3(WNT), 0, st, A);
+  hipLaunchKernelGGL(conv5x5_wgrad_bf16split_kernel<C>, dim3((unsigned)grid), dim3(WNT), 0, st, A);
   VG_CHECK_LAUNCH();
   return 0;
 }
 
 }  // namespace
 
-extern "C" size_t vg_conv5x5_wgrad_bf16x3_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride,
+extern "C" size_t vg_conv5x5_wgrad_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride,
                                                           int planes) {
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return 0;
   if (planes != 2 && planes != 3) return 0;
@@ -327,7 +327,7 @@ extern "C" size_t vg_conv5x5_wgrad_bf16x3_workspace_bytes(int B, int Cin, int H,
   return p.xp_bytes + p.gp_bytes + p.slab_bytes;
 }
 
-extern "C" int vg_conv5x5_wgrad_bf16x3(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W,
+extern "C" int vg_conv5x5_wgrad_bf16split(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W,
                                        int Cout, int stride, int planes, void* workspace, size_t workspace_bytes,
                                        void* stream) {
   if (!x || !gy || !dw || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return VG_ERR_BAD_ARG;

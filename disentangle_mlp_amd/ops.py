@@ -102,15 +102,15 @@ USE_PACKED_FILTERS = True
 # data gradients, and of the weight gradient of the wider layers): "fp32" (exact fp32 MFMA, the product default) or
 # "bf16x3" (OPT-IN: hi/lo-split operands on the bf16 MFMA, ~4e-6 relative error; layers whose
 # input channels are not a multiple of 16 stay on the fp32 kernel).  DESIGN.md section 8.
-CONV_FWD_ARITH = __import__("os").environ.get("VG_CONV_ARITH", "fp32")
-WGRAD_BF16X3 = True      # within the bf16x3 mode: False keeps the weight gradient on the exact-fp32 kernel
-if CONV_FWD_ARITH not in ("fp32", "bf16x3", "bf16x6"):
-    raise ImportError(f"VG_CONV_ARITH={CONV_FWD_ARITH!r}: expected 'fp32', 'bf16x3' or 'bf16x6'")
+CONV_ARITH = __import__("os").environ.get("VG_CONV_ARITH", "fp32")
+WGRAD_SPLIT = True      # within the bf16x3 mode: False keeps the weight gradient on the exact-fp32 kernel
+if CONV_ARITH not in ("fp32", "bf16x3", "bf16x6"):
+    raise ImportError(f"VG_CONV_ARITH={CONV_ARITH!r}: expected 'fp32', 'bf16x3' or 'bf16x6'")
 
 
 def _planes():
     """bf16 operand planes of the active arithmetic: 0 (exact fp32 MFMA), 2 (bf16x3) or 3 (bf16x6)."""
-    return {"fp32": 0, "bf16x3": 2, "bf16x6": 3}[CONV_FWD_ARITH]
+    return {"fp32": 0, "bf16x3": 2, "bf16x6": 3}[CONV_ARITH]
 _pack_scope_depth = 0
 _pack_cache = {}      # (data_ptr, transposed, stride, shape) -> [valid, version, packed tensor]
 _pack_scratch = {}    # (device, stream, numel) -> tensor, for un-cached packs
@@ -153,7 +153,7 @@ def invalidate_packed_filters(params=None):
 def _packed_filter(lib, w, cout, cin, transposed, stride):
     bf16x3 = transposed >= 2                      # 2 / 3: split-bf16 pack of the opt-in modes (conv / transposed conv)
     planes = _planes()
-    n = lib.vg_conv5x5_packed_bf16x3_bytes(cout, cin, planes) // 4 if bf16x3 else lib.vg_conv5x5_packed_floats(cout, cin)
+    n = lib.vg_conv5x5_packed_bf16split_bytes(cout, cin, planes) // 4 if bf16x3 else lib.vg_conv5x5_packed_floats(cout, cin)
     if _pack_scope_depth > 0:
         key = (w.data_ptr(), transposed, stride, tuple(w.shape), planes if bf16x3 else 0)
         ent = _pack_cache.get(key)
@@ -169,8 +169,8 @@ def _packed_filter(lib, w, cout, cin, transposed, stride):
         if buf is None:
             buf = _pack_scratch[skey] = torch.empty(n, dtype=torch.float32, device=w.device)
     if bf16x3:
-        check(lib.vg_conv5x5_pack_bf16x3(w.data_ptr(), buf.data_ptr(), cout, cin, transposed - 2, stride, planes,
-                                         _stream()), "vg_conv5x5_pack_bf16x3")
+        check(lib.vg_conv5x5_pack_bf16split(w.data_ptr(), buf.data_ptr(), cout, cin, transposed - 2, stride, planes,
+                                         _stream()), "vg_conv5x5_pack_bf16split")
     else:
         check(lib.vg_conv5x5_pack(w.data_ptr(), buf.data_ptr(), cout, cin, transposed, stride, _stream()),
               "vg_conv5x5_pack")
@@ -192,12 +192,12 @@ def conv5x5_fwd(x, w, bias, stride):
     y = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
     if _planes() and Cin % 16 == 0:
         pk = _packed_filter(lib, w, Cout, Cin, 2, 1)
-        need = lib.vg_conv5x5_fwd_bf16x3_workspace_bytes(B, Cin, H, W, Cout, stride)    # split-K slabs, deep-K layers only
+        need = lib.vg_conv5x5_fwd_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride)    # split-K slabs, deep-K layers only
         ws = workspace(need, x.device) if need else None
         with _timed(("conv_fwd", B, Cin, H, W, Cout, stride)):
-            check(lib.vg_conv5x5_fwd_bf16x3(x.data_ptr(), pk.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W,
+            check(lib.vg_conv5x5_fwd_bf16split(x.data_ptr(), pk.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W,
                                             Cout, stride, _planes(), _ptr(ws), ws.numel() if need else 0, _stream()),
-                  "vg_conv5x5_fwd_bf16x3")
+                  "vg_conv5x5_fwd_bf16split")
         return y
     if USE_PACKED_FILTERS:
         pk = _packed_filter(lib, w, Cout, Cin, 0, stride)
@@ -227,8 +227,8 @@ def convT5x5_fwd(x, w, bias, stride):
     if _planes() and Cin % 16 == 0 and not thin:
         pk = _packed_filter(lib, w, Cout, Cin, 3, stride)
         with _timed(("convT_fwd", B, Cin, H, W, Cout, stride)):
-            check(lib.vg_convT5x5_fwd_bf16x3(x.data_ptr(), pk.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W,
-                                             Cout, stride, _planes(), _stream()), "vg_convT5x5_fwd_bf16x3")
+            check(lib.vg_convT5x5_fwd_bf16split(x.data_ptr(), pk.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W,
+                                             Cout, stride, _planes(), _stream()), "vg_convT5x5_fwd_bf16split")
         return y
     if USE_PACKED_FILTERS and not thin:
         pk = _packed_filter(lib, w, Cout, Cin, 1, stride)
@@ -254,13 +254,13 @@ def conv5x5_wgrad(x, gy, stride, out=None):
     dw = out if out is not None else torch.empty((Cout, Cin, 5, 5), dtype=torch.float32, device=x.device)
     # thin inputs stay on the exact-fp32 kernel: the re-layout of gy costs more than the split arithmetic saves
     # (measured: 2 planes pay off from 16 input channels, 3 planes from 128)
-    if _planes() and WGRAD_BF16X3 and Cin >= (16 if _planes() == 2 else 128):
-        need = lib.vg_conv5x5_wgrad_bf16x3_workspace_bytes(B, Cin, H, W, Cout, stride, _planes())    # 0: shape not taken
+    if _planes() and WGRAD_SPLIT and Cin >= (16 if _planes() == 2 else 128):
+        need = lib.vg_conv5x5_wgrad_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride, _planes())    # 0: shape not taken
         if need:
             ws = workspace(need, x.device)
             with _timed(("conv_wgrad", B, Cin, H, W, Cout, stride)):
-                check(lib.vg_conv5x5_wgrad_bf16x3(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout, stride,
-                                                  _planes(), ws.data_ptr(), ws.numel(), _stream()), "vg_conv5x5_wgrad_bf16x3")
+                check(lib.vg_conv5x5_wgrad_bf16split(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout, stride,
+                                                  _planes(), ws.data_ptr(), ws.numel(), _stream()), "vg_conv5x5_wgrad_bf16split")
             return dw
     need = lib.vg_conv5x5_wgrad_workspace_bytes(B, Cin, H, W, Cout, stride)
     ws = workspace(need, x.device)

@@ -89,26 +89,26 @@ int vg_convT5x5_fwd_packed(const float* x, const float* packed, const float* bia
  *               (the exact-fp32 kernels: 5e-7..1e-6);
  *   planes = 3  hi/mid/lo = the whole 24-bit mantissa, 6 MFMAs per product ("bf16x6"): every dropped
  *               term is below 2^-24 -- fp32-equivalent.
- * Requires Cin % 16 == 0.  `packed` holds vg_conv5x5_packed_bf16x3_bytes(Cout, Cin, planes) bytes
- * (16-byte aligned), written by vg_conv5x5_pack_bf16x3 once per weight version:
- *   transposed = 0: from w[Cout,Cin,5,5] for vg_conv5x5_fwd_bf16x3 (stride ignored);
- *   transposed = 1: from w[Cin,Cout,5,5] for vg_convT5x5_fwd_bf16x3 with the SAME stride. */
-int vg_debug_set_conv_bf16x3_tile(int variant);   /* tuning only: 0 = 128x128, 1 = 64x128, 2 = 64x64, 3 = 32x128, 4 = 32x256 (transposed), -1 = heuristic */
-size_t vg_conv5x5_packed_bf16x3_bytes(int Cout, int Cin, int planes);
-int vg_conv5x5_pack_bf16x3(const float* w, void* packed, int Cout, int Cin, int transposed, int stride,
+ * Requires Cin % 16 == 0.  `packed` holds vg_conv5x5_packed_bf16split_bytes(Cout, Cin, planes) bytes
+ * (16-byte aligned), written by vg_conv5x5_pack_bf16split once per weight version:
+ *   transposed = 0: from w[Cout,Cin,5,5] for vg_conv5x5_fwd_bf16split (stride ignored);
+ *   transposed = 1: from w[Cin,Cout,5,5] for vg_convT5x5_fwd_bf16split with the SAME stride. */
+int vg_debug_set_conv_bf16split_tile(int variant);   /* tuning only: 0 = 128x128, 1 = 64x128, 2 = 64x64, 3 = 32x128, 4 = 32x256 (transposed), -1 = heuristic */
+size_t vg_conv5x5_packed_bf16split_bytes(int Cout, int Cin, int planes);
+int vg_conv5x5_pack_bf16split(const float* w, void* packed, int Cout, int Cin, int transposed, int stride,
                            int planes, void* stream);
-size_t vg_conv5x5_fwd_bf16x3_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride);   /* 0 for most shapes */
-int vg_conv5x5_fwd_bf16x3(const float* x, const void* packed, const float* bias, float* y,
+size_t vg_conv5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride);   /* 0 for most shapes */
+int vg_conv5x5_fwd_bf16split(const float* x, const void* packed, const float* bias, float* y,
                           int B, int Cin, int H, int W, int Cout, int stride, int planes,
                           void* workspace, size_t workspace_bytes, void* stream);
-int vg_convT5x5_fwd_bf16x3(const float* x, const void* packed, const float* bias, float* y,
+int vg_convT5x5_fwd_bf16split(const float* x, const void* packed, const float* bias, float* y,
                            int B, int Cin, int H, int W, int Cout, int stride, int planes, void* stream);
 /* vg_conv5x5_wgrad in the same opt-in arithmetic.  The reduction runs over images in groups of 16
  * (operands re-laid batch-innermost inside the call; B is zero-padded to a multiple of 16); needs
  * OH % 4 == 0 (planes = 2) or OH % 2 == 0 (planes = 3) and OW % 8 == 0 -- the workspace query returns 0 for shapes it does not take
  * (use vg_conv5x5_wgrad).  workspace: 16-byte aligned. */
-size_t vg_conv5x5_wgrad_bf16x3_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride, int planes);
-int vg_conv5x5_wgrad_bf16x3(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W,
+size_t vg_conv5x5_wgrad_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride, int planes);
+int vg_conv5x5_wgrad_bf16split(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W,
                             int Cout, int stride, int planes, void* workspace, size_t workspace_bytes,
                             void* stream);
 

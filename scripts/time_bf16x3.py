@@ -34,13 +34,13 @@ for name, cin, cout, h, s in L:
     ref = O.conv5x5(x[:2].cpu(), w.cpu(), None, s)
     res = []
     for mode, var in (("fp32", -1), ("bf16x3", 0), ("bf16x3", 1), ("bf16x3", 2), ("bf16x3", 3), ("bf16x3", -1)):
-        ops.CONV_FWD_ARITH = mode
-        lib.vg_debug_set_conv_bf16x3_tile(var)
+        ops.CONV_ARITH = mode
+        lib.vg_debug_set_conv_bf16split_tile(var)
         y = ops.conv5x5_fwd(x, w, None, s)
         err = float((y[:2].cpu().double() - ref).norm() / ref.norm())
         ms = timeit(lambda: ops.conv5x5_fwd(x, w, None, s))
         res.append(f"{mode if mode == 'fp32' else 'x3/v%d' % var}: {ms*1e3:5.0f}us {gf/ms:5.1f}TF e{err:.0e}")
-    ops.CONV_FWD_ARITH = "fp32"
+    ops.CONV_ARITH = "fp32"
     print(f"{name:9s} {gf:5.1f} GF  " + "   ".join(res), flush=True)
 
 TR = [("dec.d1", 256, 256, 8), ("dec.d2", 256, 128, 16), ("dec.d3", 128, 32, 32), ("enc.f6dg", 256, 128, 8),
@@ -52,14 +52,14 @@ for name, cin, cout, h in TR:
     ref = O.convT5x5(x[:2].cpu(), w.cpu(), None, 2)
     res = []
     for mode, var in (("fp32", -1), ("bf16x3", 1), ("bf16x3", 2), ("bf16x3", 3), ("bf16x3", 4), ("bf16x3", -1)):
-        ops.CONV_FWD_ARITH = mode
-        lib.vg_debug_set_conv_bf16x3_tile(var)
+        ops.CONV_ARITH = mode
+        lib.vg_debug_set_conv_bf16split_tile(var)
         y = ops.convT5x5_fwd(x, w, None, 2)
         err = float((y[:2].cpu().double() - ref).norm() / ref.norm())
         ms = timeit(lambda: ops.convT5x5_fwd(x, w, None, 2))
         res.append(f"{mode if mode == 'fp32' else 'x3/v%d' % var}: {ms*1e3:5.0f}us {gf/ms:5.1f}TF e{err:.0e}")
-    ops.CONV_FWD_ARITH = "fp32"
-    lib.vg_debug_set_conv_bf16x3_tile(-1)
+    ops.CONV_ARITH = "fp32"
+    lib.vg_debug_set_conv_bf16split_tile(-1)
     print(f"TR {name:9s} {gf:5.1f} GF  " + "   ".join(res), flush=True)
 
 WG = [("dis.c3", 32, 128, 64, 2), ("dis.c6", 128, 256, 32, 2), ("dis.c9", 256, 256, 16, 2), ("enc.f3", 64, 128, 32, 2),
@@ -71,12 +71,12 @@ for name, cin, cout, h, s in WG:
     res = []
     ref = None
     for mode in ("fp32", "bf16x3"):
-        ops.CONV_FWD_ARITH = mode
+        ops.CONV_ARITH = mode
         out = ops.conv5x5_wgrad(x, gy, s)
         if ref is None:
             ref = out.double()
         err = float((out.double() - ref).norm() / ref.norm())
         ms = timeit(lambda: ops.conv5x5_wgrad(x, gy, s))
         res.append(f"{mode}: {ms*1e3:5.0f}us {gf/ms:5.1f}TF (vs fp32 kernel {err:.0e})")
-    ops.CONV_FWD_ARITH = "fp32"
+    ops.CONV_ARITH = "fp32"
     print(f"WGRAD {name:7s} {gf:5.1f} GF  " + "   ".join(res), flush=True)

@@ -19,7 +19,7 @@ for name, cin, cout, h, s in [("dis.c3", 32, 128, 64, 2), ("dis.c6", 128, 256, 3
     ref = O.conv5x5(x[:2].cpu(), w.cpu(), None, s)
     res=[]
     for mode in ("fp32", "bf16x3", "bf16x6"):
-        ops.CONV_FWD_ARITH = mode
+        ops.CONV_ARITH = mode
         y = ops.conv5x5_fwd(x, w, None, s)
         err = float((y[:2].cpu().double() - ref).norm() / ref.norm())
         ms = timeit(lambda: ops.conv5x5_fwd(x, w, None, s))
@@ -31,7 +31,7 @@ for name, cin, cout, h in [("dec.d1", 256, 256, 8), ("dec.d2", 256, 128, 16), ("
     ref = O.convT5x5(x[:2].cpu(), w.cpu(), None, 2)
     res=[]
     for mode in ("fp32", "bf16x3", "bf16x6"):
-        ops.CONV_FWD_ARITH = mode
+        ops.CONV_ARITH = mode
         y = ops.convT5x5_fwd(x, w, None, 2)
         err = float((y[:2].cpu().double() - ref).norm() / ref.norm())
         ms = timeit(lambda: ops.convT5x5_fwd(x, w, None, 2))
@@ -42,7 +42,7 @@ for name, cin, cout, h, s in [("dis.c3", 32, 128, 64, 2), ("dis.c6", 128, 256, 3
     gf = 2.0 * B * (h // s) ** 2 * cin * cout * 25 / 1e9
     res = []
     for mode in ("fp32", "bf16x3", "bf16x6"):
-        ops.CONV_FWD_ARITH = mode
+        ops.CONV_ARITH = mode
         ms = timeit(lambda: ops.conv5x5_wgrad(x, gy, s))
         res.append(f"{mode}: {ms*1e3:5.0f}us {gf/ms:5.1f}TF")
     print(f"WGRAD {name:8s} " + "   ".join(res), flush=True)

@@ -6,8 +6,8 @@ import torch
 from disentangle_mlp_amd import ops
 from disentangle_mlp_amd.trainer import BetaVAEGANTrainer
 if len(sys.argv) > 1:
-    ops.CONV_FWD_ARITH = sys.argv[1]          # "fp32" (default) or "bf16x3"
-print("convolution arithmetic:", ops.CONV_FWD_ARITH)
+    ops.CONV_ARITH = sys.argv[1]          # "fp32" (default) or "bf16x3"
+print("convolution arithmetic:", ops.CONV_ARITH)
 tr = BetaVAEGANTrainer(beta=25.0)
 g = torch.Generator().manual_seed(7)
 B = 128

@@ -422,7 +422,7 @@ def test_packed_filter_bad_args(H):
     (3, 16, 32, 16, 16, 2), (2, 32, 128, 64, 64, 2), (2, 128, 256, 32, 32, 2), (5, 48, 70, 13, 9, 2),
     (3, 16, 130, 16, 24, 1), (2, 32, 3, 64, 64, 1), (1, 256, 256, 16, 16, 2), (4, 64, 40, 8, 8, 1)])
 def test_conv_fwd_bf16x3(H, B, Cin, Cout, Hs, Ws, stride):
-    """OPT-IN mode (ops.CONV_FWD_ARITH = "bf16x3"): hi/lo-split operands, hi*hi + hi*lo + lo*hi on the
+    """OPT-IN mode (ops.CONV_ARITH = "bf16x3"): hi/lo-split operands, hi*hi + hi*lo + lo*hi on the
     bf16 MFMA, fp32 accumulation.  Stated tolerance: 2e-5 relative L2 against the fp64 oracle (measured
     ~4e-6; the exact-fp32 default is held to 3e-6)."""
     g = torch.Generator().manual_seed(9)
@@ -430,13 +430,13 @@ def test_conv_fwd_bf16x3(H, B, Cin, Cout, Hs, Ws, stride):
     w = torch.randn(Cout, Cin, 5, 5, generator=g) * 0.05
     bias = torch.randn(Cout, generator=g)
     ref = O.conv5x5(x, w, bias, stride)
-    prev_arith = H.CONV_FWD_ARITH
+    prev_arith = H.CONV_ARITH
     try:
-        H.CONV_FWD_ARITH = "bf16x3"
+        H.CONV_ARITH = "bf16x3"
         y = H.conv5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), stride)
         y2 = H.conv5x5_fwd(x.cuda(), w.cuda(), None, stride)
     finally:
-        H.CONV_FWD_ARITH = prev_arith
+        H.CONV_ARITH = prev_arith
     assert_close(y, ref, 2e-5, "bf16x3 fwd")
     assert_close(y2, O.conv5x5(x, w, None, stride), 2e-5, "bf16x3 fwd, no bias")
     e32 = rel_l2(H.conv5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), stride), ref)
@@ -445,12 +445,12 @@ def test_conv_fwd_bf16x3(H, B, Cin, Cout, Hs, Ws, stride):
 
 def test_conv_fwd_bf16x3_falls_back_when_cin_not_multiple_of_16(H):
     x, w = _rand(2, 3, 16, 16, seed=1), 0.1 * _rand(8, 3, 5, 5, seed=2)
-    prev_arith = H.CONV_FWD_ARITH
+    prev_arith = H.CONV_ARITH
     try:
-        H.CONV_FWD_ARITH = "bf16x3"
+        H.CONV_ARITH = "bf16x3"
         y = H.conv5x5_fwd(x.cuda(), w.cuda(), None, 2)
     finally:
-        H.CONV_FWD_ARITH = prev_arith
+        H.CONV_ARITH = prev_arith
     assert_close(y, O.conv5x5(x, w, None, 2), 3e-6, "fallback to the fp32 kernel")   # Cin = 3: always the fp32 kernel
 
 
@@ -467,32 +467,32 @@ def test_convT_fwd_bf16x3(H, B, Cin, Cout, Hs, Ws, stride):
     w = torch.randn(Cin, Cout, 5, 5, generator=g) * 0.05
     bias = torch.randn(Cout, generator=g)
     ref = O.convT5x5(x, w, bias, stride)
-    prev_arith = H.CONV_FWD_ARITH
+    prev_arith = H.CONV_ARITH
     try:
-        H.CONV_FWD_ARITH = "bf16x3"
+        H.CONV_ARITH = "bf16x3"
         for variant in (-1, 0, 1, 2, 3, 4):
-            lib.vg_debug_set_conv_bf16x3_tile(variant)
+            lib.vg_debug_set_conv_bf16split_tile(variant)
             assert_close(H.convT5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), stride), ref, 2e-5, f"bf16x3 convT tile {variant}")
     finally:
-        H.CONV_FWD_ARITH = prev_arith
-        lib.vg_debug_set_conv_bf16x3_tile(-1)
+        H.CONV_ARITH = prev_arith
+        lib.vg_debug_set_conv_bf16split_tile(-1)
 
 
 def test_conv_fwd_bf16x3_every_tile(H):
     from disentangle_mlp_amd import _lib
     lib = _lib.load()
-    prev_arith = H.CONV_FWD_ARITH
+    prev_arith = H.CONV_ARITH
     try:
-        H.CONV_FWD_ARITH = "bf16x3"
+        H.CONV_ARITH = "bf16x3"
         for (B, Cin, Cout, Hs, Ws, s) in ((3, 16, 70, 16, 24, 2), (5, 32, 33, 8, 8, 1), (2, 16, 140, 40, 72, 2)):
             x, w = _rand(B, Cin, Hs, Ws, seed=50), 0.1 * _rand(Cout, Cin, 5, 5, seed=51)
             ref = O.conv5x5(x, w, None, s)
             for variant in (0, 1, 2, 3):
-                lib.vg_debug_set_conv_bf16x3_tile(variant)
+                lib.vg_debug_set_conv_bf16split_tile(variant)
                 assert_close(H.conv5x5_fwd(x.cuda(), w.cuda(), None, s), ref, 2e-5, f"bf16x3 fwd tile {variant}")
     finally:
-        H.CONV_FWD_ARITH = prev_arith
-        lib.vg_debug_set_conv_bf16x3_tile(-1)
+        H.CONV_ARITH = prev_arith
+        lib.vg_debug_set_conv_bf16split_tile(-1)
 
 
 @pytest.mark.parametrize("B,Cin,Cout,Hs,Ws,stride", [
@@ -508,30 +508,30 @@ def test_conv_wgrad_bf16x3(H, B, Cin, Cout, Hs, Ws, stride):
     OH, OW = (Hs - 1) // stride + 1, (Ws - 1) // stride + 1
     gy = torch.randn(B, Cout, OH, OW, generator=g)
     _, gw_ref = O.conv5x5_grads(x, w, gy, stride)
-    prev_arith = H.CONV_FWD_ARITH
+    prev_arith = H.CONV_ARITH
     try:
-        H.CONV_FWD_ARITH = "bf16x3"
+        H.CONV_ARITH = "bf16x3"
         gw = H.conv5x5_wgrad(x.cuda(), gy.cuda(), stride)
     finally:
-        H.CONV_FWD_ARITH = prev_arith
+        H.CONV_ARITH = prev_arith
     assert_close(gw, gw_ref, 2e-5, "bf16x3 wgrad")
 
 
 def test_conv_wgrad_bf16x3_unsupported_shape_falls_back(H):
     from disentangle_mlp_amd import _lib
     lib = _lib.load()
-    assert lib.vg_conv5x5_wgrad_bf16x3_workspace_bytes(4, 8, 10, 10, 8, 2, 2) == 0     # 5 x 5 outputs
-    assert lib.vg_conv5x5_wgrad_bf16x3_workspace_bytes(4, 8, 16, 16, 8, 2, 2) > 0
-    assert lib.vg_conv5x5_wgrad_bf16x3_workspace_bytes(4, 8, 12, 16, 8, 2, 3) > 0      # 6 x 8 outputs: 3 planes tile 2 x 8
-    assert lib.vg_conv5x5_wgrad_bf16x3_workspace_bytes(4, 8, 12, 16, 8, 2, 2) == 0
+    assert lib.vg_conv5x5_wgrad_bf16split_workspace_bytes(4, 8, 10, 10, 8, 2, 2) == 0     # 5 x 5 outputs
+    assert lib.vg_conv5x5_wgrad_bf16split_workspace_bytes(4, 8, 16, 16, 8, 2, 2) > 0
+    assert lib.vg_conv5x5_wgrad_bf16split_workspace_bytes(4, 8, 12, 16, 8, 2, 3) > 0      # 6 x 8 outputs: 3 planes tile 2 x 8
+    assert lib.vg_conv5x5_wgrad_bf16split_workspace_bytes(4, 8, 12, 16, 8, 2, 2) == 0
     x, gy = _rand(2, 3, 10, 10, seed=3), _rand(2, 4, 5, 5, seed=4)
     w = 0.1 * _rand(4, 3, 5, 5, seed=5)
-    prev_arith = H.CONV_FWD_ARITH
+    prev_arith = H.CONV_ARITH
     try:
-        H.CONV_FWD_ARITH = "bf16x3"
+        H.CONV_ARITH = "bf16x3"
         gw = H.conv5x5_wgrad(x.cuda(), gy.cuda(), 2)
     finally:
-        H.CONV_FWD_ARITH = prev_arith
+        H.CONV_ARITH = prev_arith
     assert_close(gw, O.conv5x5_grads(x, w, gy, 2)[1], 3e-6, "fallback")
 
 
@@ -541,19 +541,19 @@ def test_conv_fwd_bf16x3_split_k(H):
     from disentangle_mlp_amd import _lib
     lib = _lib.load()
     for (B, Cin, Cout, Hs, s) in ((16, 256, 256, 16, 2), (8, 144, 200, 8, 1), (32, 128, 130, 16, 2)):
-        assert lib.vg_conv5x5_fwd_bf16x3_workspace_bytes(B, Cin, Hs, Hs, Cout, s) > 0, (B, Cin, Cout)
+        assert lib.vg_conv5x5_fwd_bf16split_workspace_bytes(B, Cin, Hs, Hs, Cout, s) > 0, (B, Cin, Cout)
         g = torch.Generator().manual_seed(13)
         x = torch.randn(B, Cin, Hs, Hs, generator=g)
         w = torch.randn(Cout, Cin, 5, 5, generator=g) * 0.03
         bias = torch.randn(Cout, generator=g)
-        prev_arith = H.CONV_FWD_ARITH
+        prev_arith = H.CONV_ARITH
         try:
-            H.CONV_FWD_ARITH = "bf16x3"
+            H.CONV_ARITH = "bf16x3"
             y = H.conv5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), s)
         finally:
-            H.CONV_FWD_ARITH = prev_arith
+            H.CONV_ARITH = prev_arith
         assert_close(y, O.conv5x5(x, w, bias, s), 2e-5, f"split-K {B} {Cin} {Cout}")
-    assert lib.vg_conv5x5_fwd_bf16x3_workspace_bytes(128, 128, 32, 32, 256, 2) == 0      # large grid: no split
+    assert lib.vg_conv5x5_fwd_bf16split_workspace_bytes(128, 128, 32, 32, 256, 2) == 0      # large grid: no split
 
 
 # ------------------------------------------------------------------ opt-in bf16x6 (fp32-equivalent) mode
@@ -561,7 +561,7 @@ def test_conv_fwd_bf16x3_split_k(H):
     (3, 16, 32, 16, 16, 2), (2, 128, 256, 32, 32, 2), (5, 48, 70, 13, 9, 2), (3, 16, 130, 16, 24, 1),
     (16, 256, 256, 16, 16, 2), (20, 32, 128, 16, 32, 2)])
 def test_bf16x6_is_fp32_equivalent(H, B, Cin, Cout, Hs, Ws, stride):
-    """ops.CONV_FWD_ARITH = "bf16x6": operands split into three bf16 planes (8 + 8 + 8 mantissa bits, exact),
+    """ops.CONV_ARITH = "bf16x6": operands split into three bf16 planes (8 + 8 + 8 mantissa bits, exact),
     6 products per multiply, fp32 accumulation.  Held to the SAME 3e-6 as the exact-fp32 kernels, for the
     forward, transposed (= data gradient) and weight-gradient kernels."""
     g = torch.Generator().manual_seed(14)
@@ -572,9 +572,9 @@ def test_bf16x6_is_fp32_equivalent(H, B, Cin, Cout, Hs, Ws, stride):
     y_ref = O.conv5x5(x, w, bias, stride)
     gy = torch.randn(*y_ref.shape, generator=g)
     gx_ref, gw_ref = O.conv5x5_grads(x, w, gy, stride)
-    prev_arith = H.CONV_FWD_ARITH
+    prev_arith = H.CONV_ARITH
     try:
-        H.CONV_FWD_ARITH = "bf16x6"
+        H.CONV_ARITH = "bf16x6"
         assert_close(H.conv5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), stride), y_ref, 3e-6, "bf16x6 fwd")
         assert_close(H.convT5x5_fwd(x.cuda(), wt.cuda(), bias.cuda(), stride), O.convT5x5(x, wt, bias, stride), 3e-6,
                      "bf16x6 convT")
@@ -582,4 +582,4 @@ def test_bf16x6_is_fp32_equivalent(H, B, Cin, Cout, Hs, Ws, stride):
             assert_close(H.convT5x5_fwd(gy.cuda(), w.cuda(), None, stride), gx_ref, 3e-6, "bf16x6 dgrad")
         assert_close(H.conv5x5_wgrad(x.cuda(), gy.cuda(), stride), gw_ref, 3e-6, "bf16x6 wgrad")
     finally:
-        H.CONV_FWD_ARITH = prev_arith
+        H.CONV_ARITH = prev_arith

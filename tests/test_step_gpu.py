@@ -120,14 +120,14 @@ def test_betavaegan_gradients_vs_live_oracle(T, arith, loss_tol, grad_tol):
     from disentangle_mlp_amd import ops
     tr = T.BetaVAEGANTrainer(beta=25.0, lr=0.0)
     got_g = {}
-    prev_arith = ops.CONV_FWD_ARITH
+    prev_arith = ops.CONV_ARITH
     try:
-        ops.CONV_FWD_ARITH = arith
+        ops.CONV_ARITH = arith
         out = tr.step(*(b[k].float().cuda() for k in ("data", "noise", "eps2", "eps3")),
                       grad_hook=lambda ph, net: got_g.__setitem__(
                           ph, {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}))
     finally:
-        ops.CONV_FWD_ARITH = prev_arith
+        ops.CONV_ARITH = prev_arith
     for k in ("errD_real", "errD_fake", "errG_fake", "errG_recon", "sim", "mse_dec", "kld", "mse_enc"):
         assert close(float(out[k]), ref_l[k], loss_tol), (k, float(out[k]), ref_l[k])
     for ph, key in (("D", "d"), ("EG2", "eg"), ("EG3", "eg")):
