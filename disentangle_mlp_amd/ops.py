@@ -98,12 +98,15 @@ def reserve_workspace(nbytes, device):
 # (a few microseconds); inside one -- the trainer opens it around an iteration, where it
 # alone decides when weights change -- a pack is reused until `invalidate_packed_filters()`.
 USE_PACKED_FILTERS = True
-# Arithmetic of the convolution / transposed-convolution forward kernels (and so of each other's
-# data gradients, and of the weight gradient of the wider layers): "fp32" (exact fp32 MFMA, the product default) or
-# "bf16x3" (OPT-IN: hi/lo-split operands on the bf16 MFMA, ~4e-6 relative error; layers whose
-# input channels are not a multiple of 16 stay on the fp32 kernel).  DESIGN.md section 8.
+# Arithmetic of the three convolution kernels (forward, transposed = data gradient, weight gradient):
+#   "fp32"    exact fp32-input MFMA -- the product default;
+#   "bf16x6"  OPT-IN: every fp32 operand split exactly into 3 bf16 planes, 6 bf16 MFMAs per multiply, fp32
+#             accumulation: fp32-equivalent (held to the same tolerances), ~1.25x the fp32 iteration rate;
+#   "bf16x3"  OPT-IN: 2 planes (hi/lo), 3 MFMAs per multiply, ~4.5e-6 relative error per convolution, ~1.6x.
+# Layers whose input channels are not a multiple of 16 (the 3-channel edges) always run the fp32 kernels.
+# Set here, or with VG_CONV_ARITH in the environment.  DESIGN.md section 8 item 1.
 CONV_ARITH = __import__("os").environ.get("VG_CONV_ARITH", "fp32")
-WGRAD_SPLIT = True      # within the bf16x3 mode: False keeps the weight gradient on the exact-fp32 kernel
+WGRAD_SPLIT = True      # within the split modes: False keeps the weight gradient on the exact-fp32 kernel
 if CONV_ARITH not in ("fp32", "bf16x3", "bf16x6"):
     raise ImportError(f"VG_CONV_ARITH={CONV_ARITH!r}: expected 'fp32', 'bf16x3' or 'bf16x6'")
 
@@ -111,6 +114,8 @@ if CONV_ARITH not in ("fp32", "bf16x3", "bf16x6"):
 def _planes():
     """bf16 operand planes of the active arithmetic: 0 (exact fp32 MFMA), 2 (bf16x3) or 3 (bf16x6)."""
     return {"fp32": 0, "bf16x3": 2, "bf16x6": 3}[CONV_ARITH]
+
+
 _pack_scope_depth = 0
 _pack_cache = {}      # (data_ptr, transposed, stride, shape) -> [valid, version, packed tensor]
 _pack_scratch = {}    # (device, stream, numel) -> tensor, for un-cached packs
