@@ -30,6 +30,7 @@ from torch import optim
 
 from . import functional as F
 from . import ops
+from .optim import HipAdam
 from .model import VAE, Discriminator_celeba, Generator_celeba, weights_init
 
 
@@ -149,10 +150,14 @@ class FlatGrads:
 
 
 def _make_adam(params, lr, fused, capturable=False):
-    """torch.optim.Adam with the reference's defaults (new_betavaegan.py:49-50).  ``capturable`` keeps the
-    step counters on the device so that a whole iteration can be captured in a HIP graph."""
+    """Adam with the reference's defaults (new_betavaegan.py:49-50).  On the GPU the step runs on the
+    hand-written kernel (optim.HipAdam, a torch.optim.Adam subclass: identical state_dict); ``capturable``
+    -- step counters on the device so that a whole iteration can be captured in a HIP graph -- and CPU
+    construction use torch's own implementations."""
+    if fused and not capturable:
+        return HipAdam(params, lr=lr)
     if fused:
-        return optim.Adam(params, lr=lr, fused=True, capturable=capturable)
+        return optim.Adam(params, lr=lr, fused=True, capturable=True)
     return optim.Adam(params, lr=lr, capturable=capturable)
 
 

@@ -189,6 +189,22 @@ size_t vg_sqdiff_workspace_bytes(size_t n);
 int vg_bce_loss(const float* p, float target, float* loss, float* gp, int B, float divisor,
                 float gscale, void* stream);
 
+/* ---- Adam (experiments/new_betavaegan.py:49-50: optim.Adam defaults, stepped 3x per iteration)
+ * For each tensor: m += (1-beta1)(g-m); v = beta2 v + (1-beta2) g^2;
+ * p -= (lr / bias_correction1) * m / (sqrt(v) / bias_correction2_sqrt + eps),
+ * with bias_correction1 = 1 - beta1^step and bias_correction2_sqrt = sqrt(1 - beta2^step) computed by
+ * the caller (double).  `tensors` is a HOST array of DEVICE pointers (fp32, n elements each);
+ * any number of tensors, 24 per kernel launch.  No weight decay / amsgrad / maximize. */
+typedef struct {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  size_t n;
+} VgAdamTensor;
+int vg_adam_step(const VgAdamTensor* tensors, int count, double lr, double beta1, double beta2, double eps,
+                 double bias_correction1, double bias_correction2_sqrt, void* stream);
+
 /* ---- image I/O either side of the step -----------------
  * Input pipeline of dataloader/dataset.py:37-43 (ToTensor + Normalize(mean, std) of a
  * shuffled batch) on a uint8 image cache resident in HBM, layout [N][H][W][C] as decoded:

@@ -281,3 +281,50 @@ def test_load_accepts_prefixless_discriminator_keys(T):
     assert tr2.load(ck) == 3
     for (k, a), (_, b) in zip(tr.netD.state_dict().items(), tr2.netD.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_hip_adam_matches_torch_adam_and_shares_checkpoints(T):
+    """optim.HipAdam (vg_adam_step) against torch.optim.Adam on the same gradients for 4 steps: parameters
+    and moments agree to a few ulp; state_dict round-trips in both directions."""
+    from disentangle_mlp_amd.optim import HipAdam
+    g = torch.Generator().manual_seed(21)
+    shapes = [(7,), (33, 5), (256, 128, 5, 5), (2048, 1031), (3,), (64, 3, 5, 5)] + [(5, 5)] * 30     # > 24 tensors: 2 launches
+    ps_a = [torch.nn.Parameter(torch.randn(*s, generator=g).cuda()) for s in shapes]
+    ps_b = [torch.nn.Parameter(p.detach().clone()) for p in ps_a]
+    oa, ob = HipAdam(ps_a, lr=1e-3), torch.optim.Adam(ps_b, lr=1e-3)
+    assert isinstance(oa, torch.optim.Adam)
+    for it in range(4):
+        for pa, pb in zip(ps_a, ps_b):
+            gr = torch.randn(*pa.shape, generator=g).cuda() * (10.0 ** (it - 2))
+            pa.grad, pb.grad = gr.clone(), gr.clone()
+        if it == 2:
+            ps_a[0].grad = ps_b[0].grad = None            # a parameter without a gradient is skipped, its step too
+        oa.step()
+        ob.step()
+    for pa, pb in zip(ps_a, ps_b):
+        assert float((pa - pb).abs().max()) <= 2e-6 * max(float(pb.abs().max()), 1.0)
+        for key in ("exp_avg", "exp_avg_sq"):
+            a, b = oa.state[pa][key], ob.state[pb][key]
+            assert float((a - b).abs().max()) <= 1e-6 * max(float(b.abs().max()), 1e-30) + 1e-30, key
+        assert float(oa.state[pa]["step"]) == float(ob.state[pb]["step"])
+    # checkpoints: torch -> Hip and Hip -> torch
+    ps_c = [torch.nn.Parameter(p.detach().clone()) for p in ps_b]
+    oc = HipAdam(ps_c, lr=1e-3)
+    import copy
+    oc.load_state_dict(copy.deepcopy(ob.state_dict()))        # as through torch.save / torch.load (live dicts share tensors)
+    ps_d = [torch.nn.Parameter(p.detach().clone()) for p in ps_a]
+    od = torch.optim.Adam(ps_d, lr=1e-3)
+    od.load_state_dict(copy.deepcopy(oa.state_dict()))
+    for pc, pb, pd, pa in zip(ps_c, ps_b, ps_d, ps_a):
+        gr = torch.randn(*pc.shape, generator=g).cuda()
+        pc.grad, pb.grad, pd.grad, pa.grad = gr.clone(), gr.clone(), gr.clone(), gr.clone()
+    oc.step(); ob.step(); od.step(); oa.step()
+    for pc, pb, pd, pa in zip(ps_c, ps_b, ps_d, ps_a):
+        assert float((pc - pb).abs().max()) <= 2e-6 * max(float(pb.abs().max()), 1.0)
+        assert float((pd - pa).abs().max()) <= 2e-6 * max(float(pa.abs().max()), 1.0)
+    # weight decay is not implemented natively: falls back to torch's step, still correct
+    pe, pf = torch.nn.Parameter(torch.ones(10).cuda()), torch.nn.Parameter(torch.ones(10).cuda())
+    oe, of = HipAdam([pe], lr=1e-2, weight_decay=0.1), torch.optim.Adam([pf], lr=1e-2, weight_decay=0.1)
+    pe.grad, pf.grad = torch.ones(10).cuda(), torch.ones(10).cuda()
+    oe.step(); of.step()
+    assert torch.allclose(pe, pf)
