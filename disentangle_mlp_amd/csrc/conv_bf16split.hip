@@ -66,7 +66,7 @@ struct XCfg {
   static constexpr int NQ = cdiv(NUNIT, XNT);
   static constexpr int NCLS = (MODE == X_FWD) ? 1 : S * S;
   static_assert(TM == 32 * WP * FP, "pixel tile");
-  static_assert(WC == 1 || WC == 2, "wavefront grid");
+  static_assert(WC == 1 || WC == 2 || WC == 4, "wavefront grid");
 };
 
 struct XArgs {
@@ -388,11 +388,12 @@ int dispatch_x(const float* x, const bf16x8* w, const float* bias, float* y, int
   else if (MODE == X_FWD && Cout > 64 && px128 * cdiv(Cout, 128) >= 512) var = 0;   // transposed: 64 x 128 measured faster
   else if (px128 * cdiv(Cout, 64) >= 512) var = 1;
   if (MODE == X_FWD && g_xsplit.k > 1) var = 0;             // split-K is sized for the 128 x 128 tile
-  else if (g_x_tile_override >= 0 && g_x_tile_override <= 4 && !(g_x_tile_override == 4 && MODE == X_FWD))
+  else if (g_x_tile_override >= 0 && g_x_tile_override <= 5 && !(g_x_tile_override == 4 && MODE == X_FWD))
     var = g_x_tile_override;
   if (var == 0) return dispatch_geom<MODE, S, 2, 2, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
   if (var == 1) return dispatch_geom<MODE, S, 2, 1, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
   if (var == 3) return dispatch_geom<MODE, S, 1, 1, 1, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+  if (var == 5) return dispatch_geom<MODE, S, 4, 1, 4, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, st);   // 4 wavefronts along cout
   if constexpr (MODE == X_TR) {
     if (var == 4) return dispatch_geom<MODE, S, 1, 1, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
   }

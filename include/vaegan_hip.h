@@ -93,7 +93,7 @@ int vg_convT5x5_fwd_packed(const float* x, const float* packed, const float* bia
  * (16-byte aligned), written by vg_conv5x5_pack_bf16split once per weight version:
  *   transposed = 0: from w[Cout,Cin,5,5] for vg_conv5x5_fwd_bf16split (stride ignored);
  *   transposed = 1: from w[Cin,Cout,5,5] for vg_convT5x5_fwd_bf16split with the SAME stride. */
-int vg_debug_set_conv_bf16split_tile(int variant);   /* tuning only: 0 = 128x128, 1 = 64x128, 2 = 64x64, 3 = 32x128, 4 = 32x256 (transposed), -1 = heuristic */
+int vg_debug_set_conv_bf16split_tile(int variant);   /* tuning only: 0 = 128x128, 1 = 64x128, 2 = 64x64, 3 = 32x128, 4 = 32x256 (transposed), 5 = 128x128 with the 4 wavefronts along cout, -1 = heuristic */
 size_t vg_conv5x5_packed_bf16split_bytes(int Cout, int Cin, int planes);
 int vg_conv5x5_pack_bf16split(const float* w, void* packed, int Cout, int Cin, int transposed, int stride,
                            int planes, void* stream);

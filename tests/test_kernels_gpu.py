@@ -470,7 +470,7 @@ def test_convT_fwd_bf16x3(H, B, Cin, Cout, Hs, Ws, stride):
     prev_arith = H.CONV_ARITH
     try:
         H.CONV_ARITH = "bf16x3"
-        for variant in (-1, 0, 1, 2, 3, 4):
+        for variant in (-1, 0, 1, 2, 3, 4, 5):
             lib.vg_debug_set_conv_bf16split_tile(variant)
             assert_close(H.convT5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), stride), ref, 2e-5, f"bf16x3 convT tile {variant}")
     finally:
@@ -487,7 +487,7 @@ def test_conv_fwd_bf16x3_every_tile(H):
         for (B, Cin, Cout, Hs, Ws, s) in ((3, 16, 70, 16, 24, 2), (5, 32, 33, 8, 8, 1), (2, 16, 140, 40, 72, 2)):
             x, w = _rand(B, Cin, Hs, Ws, seed=50), 0.1 * _rand(Cout, Cin, 5, 5, seed=51)
             ref = O.conv5x5(x, w, None, s)
-            for variant in (0, 1, 2, 3):
+            for variant in (0, 1, 2, 3, 5):
                 lib.vg_debug_set_conv_bf16split_tile(variant)
                 assert_close(H.conv5x5_fwd(x.cuda(), w.cuda(), None, s), ref, 2e-5, f"bf16x3 fwd tile {variant}")
     finally:
