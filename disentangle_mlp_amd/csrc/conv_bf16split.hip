@@ -316,11 +316,10 @@ struct XSplit {
   int k;          // 1: no split
   float* slabs;   // k partial outputs
 };
-XSplit g_xsplit = {1, nullptr};   // set by the forward entry point around its dispatch (one host thread per process)
 
 template <class C>
 int launch_x(const float* x, const bf16x8* w, const float* bias, float* y, int B, int Cin, int XH, int XW, int Cout,
-             hipStream_t st) {
+             XSplit xs, hipStream_t st) {
   XArgs A;
   A.x = x; A.w = w; A.bias = bias; A.y = y;
   A.B = B; A.Cin = Cin; A.XH = XH; A.XW = XW; A.Cout = Cout; A.CoutP = (Cout + 127) & ~127;
@@ -336,19 +335,19 @@ int launch_x(const float* x, const bf16x8* w, const float* bias, float* y, int B
   A.tiles_hw = cdiv(tsh, C::TH) * A.tiles_w;
   A.ntiles_n = cdiv(Cout, C::TN);
   const long per_cls = (long)A.ntiles_n * A.tiles_hw * cdiv(B, C::NB);
-  const int ksplit = (C::MODE == X_FWD) ? g_xsplit.k : 1;
+  const int ksplit = (C::MODE == X_FWD) ? xs.k : 1;
   const long grid = per_cls * C::NCLS * ksplit;
   if (grid <= 0 || grid > 0x7fffffffL) return VG_ERR_BAD_ARG;
   A.blocks_per_cls = (int)per_cls;
   A.ksplit = ksplit;
   A.cps = cdiv(Cin / 16, ksplit);
   A.ysplit = (size_t)B * Cout * A.YH * A.YW;
-  if (ksplit > 1) A.y = g_xsplit.slabs;
+  if (ksplit > 1) A.y = xs.slabs;
   hipLaunchKernelGGL(conv5x5_bf16split_kernel<C>, dim3((unsigned)grid), dim3(XNT), 0, st, A);
   VG_CHECK_LAUNCH();
   if (ksplit > 1) {
     if (A.ysplit > 0x7fffffffUL) return VG_ERR_BAD_ARG;
-    return vg_internal_wgrad_reduce(g_xsplit.slabs, y, (int)A.ysplit, ksplit, st);   // fixed-order sum of the slabs
+    return vg_internal_wgrad_reduce(xs.slabs, y, (int)A.ysplit, ksplit, st);   // fixed-order sum of the slabs
   }
   return 0;
 }
@@ -357,21 +356,21 @@ int g_x_tile_override = -1;   // diagnostics: 0 = 128 cout x 128 px, 1 = 64 x 12
 
 template <int MODE, int S, int WC, int FC, int FP, int NP>
 int dispatch_geom(const float* x, const bf16x8* w, const float* bias, float* y, int B, int Cin, int XH, int XW,
-                  int Cout, hipStream_t st) {
+                  int Cout, XSplit xs, hipStream_t st) {
   const int tsw = (MODE == X_FWD) ? (XW - 1) / S + 1 : XW;
   constexpr int TM = 32 * (4 / WC) * FP;
   if constexpr (TM == 128) {
-    if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 4, 32, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 8, 16, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    return launch_x<XCfg<MODE, S, 2, 8, 8, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 4, 32, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+    if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 8, 16, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+    return launch_x<XCfg<MODE, S, 2, 8, 8, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
   } else if constexpr (TM == 256) {
-    if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 8, 32, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 16, 16, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    return launch_x<XCfg<MODE, S, 4, 8, 8, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 8, 32, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+    if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 16, 16, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+    return launch_x<XCfg<MODE, S, 4, 8, 8, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
   } else {
-    if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 2, 32, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 4, 16, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    return launch_x<XCfg<MODE, S, 1, 8, 8, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 2, 32, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+    if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 4, 16, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+    return launch_x<XCfg<MODE, S, 1, 8, 8, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
   }
 }
 
@@ -379,7 +378,7 @@ int dispatch_geom(const float* x, const bf16x8* w, const float* bias, float* y, 
 // 128 px, else 64 x 64; 32 cout x 128 px (4 wavefronts along the pixels) for thin outputs.
 template <int MODE, int S, int NP>
 int dispatch_x(const float* x, const bf16x8* w, const float* bias, float* y, int B, int Cin, int XH, int XW, int Cout,
-               hipStream_t st) {
+               XSplit xs, hipStream_t st) {
   const int tsw = (MODE == X_FWD) ? (XW - 1) / S + 1 : XW, tsh = (MODE == X_FWD) ? (XH - 1) / S + 1 : XH;
   const int ncls = (MODE == X_TR) ? S * S : 1;
   const long px128 = (long)cdiv(B * cdiv(tsh, 8) * cdiv(tsw, 8) * 64, 128) * ncls;
@@ -387,17 +386,17 @@ int dispatch_x(const float* x, const bf16x8* w, const float* bias, float* y, int
   if (Cout <= 32) var = (MODE == X_TR && px128 >= 1024) ? 4 : 3;      // transposed, large grid: 256 pixels per workgroup
   else if (MODE == X_FWD && Cout > 64 && px128 * cdiv(Cout, 128) >= 512) var = 0;   // transposed: 64 x 128 measured faster
   else if (px128 * cdiv(Cout, 64) >= 512) var = 1;
-  if (MODE == X_FWD && g_xsplit.k > 1) var = 0;             // split-K is sized for the 128 x 128 tile
+  if (MODE == X_FWD && xs.k > 1) var = 0;             // split-K is sized for the 128 x 128 tile
   else if (g_x_tile_override >= 0 && g_x_tile_override <= 5 && !(g_x_tile_override == 4 && MODE == X_FWD))
     var = g_x_tile_override;
-  if (var == 0) return dispatch_geom<MODE, S, 2, 2, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-  if (var == 1) return dispatch_geom<MODE, S, 2, 1, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-  if (var == 3) return dispatch_geom<MODE, S, 1, 1, 1, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-  if (var == 5) return dispatch_geom<MODE, S, 4, 1, 4, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, st);   // 4 wavefronts along cout
+  if (var == 0) return dispatch_geom<MODE, S, 2, 2, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+  if (var == 1) return dispatch_geom<MODE, S, 2, 1, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+  if (var == 3) return dispatch_geom<MODE, S, 1, 1, 1, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+  if (var == 5) return dispatch_geom<MODE, S, 4, 1, 4, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);   // 4 wavefronts along cout
   if constexpr (MODE == X_TR) {
-    if (var == 4) return dispatch_geom<MODE, S, 1, 1, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    if (var == 4) return dispatch_geom<MODE, S, 1, 1, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
   }
-  return dispatch_geom<MODE, S, 2, 1, 1, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+  return dispatch_geom<MODE, S, 2, 1, 1, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
 }
 
 // packed[class][chunk][tap][plane][k-block][CoutP] x 8 bf16 (+ one zero step at the end).
@@ -514,16 +513,12 @@ extern "C" int vg_conv5x5_fwd_bf16split(const float* x, const void* packed, cons
   const int k = fwd_ksplit(B, Cin, H, W, Cout, stride);
   if (k > 1 && (!workspace || workspace_bytes < vg_conv5x5_fwd_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride)))
     return VG_ERR_WORKSPACE;
-  g_xsplit = {k, (float*)workspace};
-  int rc;
+  const XSplit xs = {k, (float*)workspace};
   if (planes == 2)
-    rc = (stride == 2) ? dispatch_x<X_FWD, 2, 2>(x, w, bias, y, B, Cin, H, W, Cout, st)
-                       : dispatch_x<X_FWD, 1, 2>(x, w, bias, y, B, Cin, H, W, Cout, st);
-  else
-    rc = (stride == 2) ? dispatch_x<X_FWD, 2, 3>(x, w, bias, y, B, Cin, H, W, Cout, st)
-                       : dispatch_x<X_FWD, 1, 3>(x, w, bias, y, B, Cin, H, W, Cout, st);
-  g_xsplit = {1, nullptr};
-  return rc;
+    return (stride == 2) ? dispatch_x<X_FWD, 2, 2>(x, w, bias, y, B, Cin, H, W, Cout, xs, st)
+                         : dispatch_x<X_FWD, 1, 2>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
+  return (stride == 2) ? dispatch_x<X_FWD, 2, 3>(x, w, bias, y, B, Cin, H, W, Cout, xs, st)
+                       : dispatch_x<X_FWD, 1, 3>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
 }
 
 extern "C" int vg_convT5x5_fwd_bf16split(const float* x, const void* packed, const float* bias, float* y, int B, int Cin,
@@ -532,9 +527,9 @@ extern "C" int vg_convT5x5_fwd_bf16split(const float* x, const void* packed, con
   hipStream_t st = (hipStream_t)stream;
   const bf16x8* w = (const bf16x8*)packed;
   if (planes == 2) {
-    if (stride == 2) return dispatch_x<X_TR, 2, 2>(x, w, bias, y, B, Cin, H, W, Cout, st);
-    return dispatch_x<X_TR, 1, 2>(x, w, bias, y, B, Cin, H, W, Cout, st);
+    if (stride == 2) return dispatch_x<X_TR, 2, 2>(x, w, bias, y, B, Cin, H, W, Cout, XSplit{1, nullptr}, st);
+    return dispatch_x<X_TR, 1, 2>(x, w, bias, y, B, Cin, H, W, Cout, XSplit{1, nullptr}, st);
   }
-  if (stride == 2) return dispatch_x<X_TR, 2, 3>(x, w, bias, y, B, Cin, H, W, Cout, st);
-  return dispatch_x<X_TR, 1, 3>(x, w, bias, y, B, Cin, H, W, Cout, st);
+  if (stride == 2) return dispatch_x<X_TR, 2, 3>(x, w, bias, y, B, Cin, H, W, Cout, XSplit{1, nullptr}, st);
+  return dispatch_x<X_TR, 1, 3>(x, w, bias, y, B, Cin, H, W, Cout, XSplit{1, nullptr}, st);
 }
