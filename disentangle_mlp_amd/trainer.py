@@ -59,6 +59,8 @@ class FlatGrads:
     exchange.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): few, large messages keep
     all the rings / trees RCCL builds busy."""
 
+    exchange_when_alone = False      # tests: run the collectives even in a process group of one
+
     def __init__(self, params, bucket_bytes=8 << 20, direct_bytes=1 << 20, overlap=True):
         self.params = [p for p in params]
         self.direct = [p.numel() * 4 >= direct_bytes for p in self.params]
@@ -125,7 +127,8 @@ class FlatGrads:
         self._launched = [False] * len(self.buckets)
         self._direct_done = set()
         self._handles = []
-        self._armed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # a 1-rank group still exchanges (sum over one rank): lets a single GPU exercise the RCCL path end to end
+        self._armed = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FlatGrads.exchange_when_alone)
 
     def finish(self):
         """Reduce what did not fire from the hooks (or everything, without overlap), then make
@@ -201,7 +204,7 @@ class BetaVAEGANTrainer:
             net.zero_grad(set_to_none=True)
 
     def _exchange(self, flat):
-        if flat is not None and self.world > 1:
+        if flat is not None and (self.world > 1 or FlatGrads.exchange_when_alone):
             flat.finish()
 
     def _set_d_frozen(self, frozen):

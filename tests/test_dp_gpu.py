@@ -99,3 +99,34 @@ def test_two_rank_step_matches_two_replica_oracle():
     # moves a gradient by ~1/sqrt(#units of its layer) (a BatchNorm1d layer has only 16 x 2048
     # units here); a wrong divisor, a missing rank or a mean-instead-of-sum reduction is O(1)
     assert worst[0] <= 1e-2, worst
+
+
+def test_rccl_path_in_a_group_of_one():
+    """The exchange code over the REAL backend the multi-GPU runs use ("nccl" = RCCL): a process group of one
+    rank on this GPU, collectives forced on (FlatGrads.exchange_when_alone).  Every hook-launched in-place
+    all-reduce, the bucketed flat buffer, the async handles and their stream waits run through RCCL; a sum over
+    one rank changes nothing, so three iterations must reproduce the plain trainer bit for bit."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent("""
+        import os, sys, torch, torch.distributed as dist
+        sys.path.insert(0, os.getcwd())
+        from disentangle_mlp_amd import trainer as T
+        from oracle import steps as osteps
+        b = {k: v.cuda() for k, v in osteps.synthetic_batch(8).items()}
+        ref = T.BetaVAEGANTrainer(beta=25.0)
+        want = [{k: float(v) for k, v in ref.step(b["data"], b["noise"], b["eps2"], b["eps3"]).items()} for _ in range(3)]
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        T.FlatGrads.exchange_when_alone = True
+        tr = T.BetaVAEGANTrainer(beta=25.0, data_parallel=True)
+        got = [{k: float(v) for k, v in tr.step(b["data"], b["noise"], b["eps2"], b["eps3"]).items()} for _ in range(3)]
+        torch.cuda.synchronize()
+        assert got == want, (got, want)
+        for (k, v), (_, r) in zip(tr.netEG.state_dict().items(), ref.netEG.state_dict().items()):
+            assert torch.equal(v, r), k
+        dist.destroy_process_group()
+        print("rccl-one-rank ok")
+    """)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "rccl-one-rank ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
