@@ -226,6 +226,20 @@ __device__ __forceinline__ void bf16split_body(const XArgs& A, f32x4* lds, int b
 #pragma unroll
       for (int g = 0; g < FC; ++g) wrow[g] = wa[g] + ((size_t)ch * NTAP + ta * NTW) * wstep;
       const int rowoff = (MODE == X_FWD) ? ta * ROWU : (NTMAX - 1 - ta) * ROWU;
+      // Pinned software pipeline (hipcc otherwise sinks the prefetch loads next to their first use, one
+      // vmcnt wait per MFMA pair): at the top of a tap issue the NEXT tap's filter fragments (global) and
+      // pixel fragments (LDS, within the row), then run this tap's MFMAs on registers loaded a tap ago.
+      constexpr bool BPF = (NP == 2);      // pixel fragments one tap ahead too (3 planes: no registers left for it)
+      constexpr bool PIN = (NP == 2);      // 3 planes: pinning makes the register allocator spill; left to the compiler
+      bf16x8 bv[BPF ? 2 : 1][FP][NP];
+      auto read_b = [&](int buf, int t) {
+        const int imm = (MODE == X_TR) ? (NTMAX - 1 - t) : (C::SPLIT ? (t & 1) * COLS + (t >> 1) : t);
+#pragma unroll
+        for (int f = 0; f < FP; ++f)
+#pragma unroll
+          for (int p = 0; p < NP; ++p) bv[buf][f][p] = __builtin_bit_cast(bf16x8, lds[base_b[f] + rowoff + imm + p * 2 * IMGU]);
+      };
+      if (BPF) read_b(0, 0);
 #pragma unroll
       for (int tb = 0; tb < NTW; ++tb) {
         const int cur = tb & 1, nxt = cur ^ 1;
@@ -234,12 +248,12 @@ __device__ __forceinline__ void bf16split_body(const XArgs& A, f32x4* lds, int b
         for (int g = 0; g < FC; ++g)
 #pragma unroll
           for (int p = 0; p < NP; ++p) av[nxt][g][p] = wrow[g][(size_t)(tb + 1) * wstep + (size_t)p * 2 * CoutP];
-        const int imm = (MODE == X_TR) ? (NTMAX - 1 - tb) : (C::SPLIT ? (tb & 1) * COLS + (tb >> 1) : tb);
-        bf16x8 bv[FP][NP];
-#pragma unroll
-        for (int f = 0; f < FP; ++f)
-#pragma unroll
-          for (int p = 0; p < NP; ++p) bv[f][p] = __builtin_bit_cast(bf16x8, lds[base_b[f] + rowoff + imm + p * 2 * IMGU]);
+        if (BPF) {
+          if (tb + 1 < NTW) read_b(nxt, tb + 1);
+        } else {
+          read_b(0, tb);
+        }
+        if (PIN) __builtin_amdgcn_sched_barrier(0);
         // products with plane index sum <= NP - 1, smallest terms first; product-major so that independent
         // accumulators sit between dependent MFMAs
 #pragma unroll
@@ -249,7 +263,8 @@ __device__ __forceinline__ void bf16split_body(const XArgs& A, f32x4* lds, int b
 #pragma unroll
             for (int g = 0; g < FC; ++g)
 #pragma unroll
-              for (int f = 0; f < FP; ++f) acc[g][f] = mfma_bf16(av[cur][g][pa], bv[f][sum - pa], acc[g][f]);
+              for (int f = 0; f < FP; ++f) acc[g][f] = mfma_bf16(av[cur][g][pa], bv[BPF ? cur : 0][f][sum - pa], acc[g][f]);
+        if (PIN) __builtin_amdgcn_sched_barrier(0);
       }
       if (NTW & 1) {
 #pragma unroll
