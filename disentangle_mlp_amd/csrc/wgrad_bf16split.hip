@@ -249,6 +249,7 @@ __global__ __launch_bounds__(WNT, 2) void conv5x5_wgrad_bf16split_kernel(WXArgs 
           for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) bv[f][pl] = __builtin_bit_cast(bf16x8, lds[base_b[f] + brow + S * pw + pl * 2 * KBU]);
+          __builtin_amdgcn_sched_barrier(0);   // keep the next pixel's gy loads ahead of this pixel's MFMAs
           // products with plane index sum < NP, smallest terms first, product-major
 #pragma unroll
           for (int sum = NP - 1; sum >= 0; --sum)
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(WNT, 2) void conv5x5_wgrad_bf16split_kernel(WXArgs 
               for (int g = 0; g < 2; ++g)
 #pragma unroll
                 for (int f = 0; f < 2; ++f) acc[g][f] = mfma_bf16(av[cur][g][pa], bv[f][sum - pa], acc[g][f]);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       __syncthreads();
