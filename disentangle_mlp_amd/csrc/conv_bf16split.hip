@@ -401,6 +401,9 @@ int dispatch_x(const float* x, const bf16x8* w, const float* bias, float* y, int
   if (Cout <= 32) var = (MODE == X_TR && px128 >= 1024) ? 4 : 3;      // transposed, large grid: 256 pixels per workgroup
   else if (MODE == X_FWD && Cout > 64 && px128 * cdiv(Cout, 128) >= 512) var = 0;   // transposed: 64 x 128 measured faster
   else if (px128 * cdiv(Cout, 64) >= 512) var = 1;
+  // 3 planes: the 128 x 128 tile with the four wavefronts along cout (each loads only its own filter fragment)
+  // measured 0-15 % faster than the 2 x 2 arrangement, never slower
+  if (NP == 3 && (var == 0 || var == 1) && Cout >= 128 && px128 * cdiv(Cout, 128) >= 256) var = 5;
   if (MODE == X_FWD && xs.k > 1) var = 0;             // split-K is sized for the 128 x 128 tile
   else if (g_x_tile_override >= 0 && g_x_tile_override <= 5 && !(g_x_tile_override == 4 && MODE == X_FWD))
     var = g_x_tile_override;

@@ -101,8 +101,8 @@ USE_PACKED_FILTERS = True
 # Arithmetic of the three convolution kernels (forward, transposed = data gradient, weight gradient):
 #   "fp32"    exact fp32-input MFMA -- the product default;
 #   "bf16x6"  OPT-IN: every fp32 operand split exactly into 3 bf16 planes, 6 bf16 MFMAs per multiply, fp32
-#             accumulation: fp32-equivalent (held to the same tolerances), ~1.25x the fp32 iteration rate;
-#   "bf16x3"  OPT-IN: 2 planes (hi/lo), 3 MFMAs per multiply, ~4.5e-6 relative error per convolution, ~1.6x.
+#             accumulation: fp32-equivalent (held to the same tolerances), ~1.3x the fp32 iteration rate;
+#   "bf16x3"  OPT-IN: 2 planes (hi/lo), 3 MFMAs per multiply, ~4.5e-6 relative error per convolution, ~1.7x.
 # Layers whose input channels are not a multiple of 16 (the 3-channel edges) always run the fp32 kernels.
 # Set here, or with VG_CONV_ARITH in the environment.  DESIGN.md section 8 item 1.
 CONV_ARITH = __import__("os").environ.get("VG_CONV_ARITH", "fp32")
