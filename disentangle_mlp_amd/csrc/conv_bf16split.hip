@@ -230,7 +230,7 @@ __device__ __forceinline__ void bf16split_body(const XArgs& A, f32x4* lds, int b
       // vmcnt wait per MFMA pair): at the top of a tap issue the NEXT tap's filter fragments (global) and
       // pixel fragments (LDS, within the row), then run this tap's MFMAs on registers loaded a tap ago.
       constexpr bool BPF = (NP == 2);      // pixel fragments one tap ahead too (3 planes: no registers left for it)
-      constexpr bool PIN = (NP == 2);      // 3 planes: pinning makes the register allocator spill; left to the compiler
+      constexpr bool PIN = (NP == 2) || C::WC == 4;   // 3 planes, 2 x 2 fragments: pinning makes the allocator spill
       bf16x8 bv[BPF ? 2 : 1][FP][NP];
       auto read_b = [&](int buf, int t) {
         const int imm = (MODE == X_TR) ? (NTMAX - 1 - t) : (C::SPLIT ? (t & 1) * COLS + (t >> 1) : t);
