@@ -258,8 +258,8 @@ def conv5x5_wgrad(x, gy, stride, out=None):
         raise RuntimeError(f"conv5x5_wgrad: gy {tuple(gy.shape)} does not match x {tuple(x.shape)} stride {stride}")
     dw = out if out is not None else torch.empty((Cout, Cin, 5, 5), dtype=torch.float32, device=x.device)
     # thin inputs stay on the exact-fp32 kernel: the re-layout of gy costs more than the split arithmetic saves
-    # (measured: 2 planes pay off from 16 input channels, 3 planes from 128)
-    if _planes() and WGRAD_SPLIT and Cin >= (16 if _planes() == 2 else 128):
+    # (measured: 2 planes pay off from 16 input channels, 3 planes from 32)
+    if _planes() and WGRAD_SPLIT and Cin >= (16 if _planes() == 2 else 32):
         need = lib.vg_conv5x5_wgrad_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride, _planes())    # 0: shape not taken
         if need:
             ws = workspace(need, x.device)
