@@ -48,6 +48,7 @@ struct WXArgs {
   float* ws;
   int Cin, H, W, Cout, CoP, OH, OW;
   int mtiles, ntiles, splits, tiles_w, tiles_hw, chunks, chunks_per_split;
+  int xcd_aware;
 };
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
@@ -137,7 +138,17 @@ __global__ __launch_bounds__(WNT, 2) void conv5x5_wgrad_bf16split_kernel(WXArgs 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int kb = lane >> 5, l32 = lane & 31;
   const int wm = wid & 1, wn = wid >> 1;
+  // XCD-aware placement (workgroups are dealt round-robin over the 8 XCDs, each with its own L2): all output
+  // tiles of one K split -- they read the same gy / x chunks -- go to ONE XCD, so a chunk is fetched into one L2
+  // instead of eight.  Placement affects speed only.
   int bid = blockIdx.x;
+  {
+    const int T = A.mtiles * A.ntiles, full = (A.splits / 8) * 8 * T;
+    if (bid < full && A.xcd_aware) {
+      const int xcd = bid & 7, slot = bid >> 3;
+      bid = ((slot / T) * 8 + xcd) * T + slot % T;
+    }
+  }
   const int mt = bid % A.mtiles;
   bid /= A.mtiles;
   const int nt = bid % A.ntiles, split = bid / A.ntiles;
@@ -359,6 +370,7 @@ extern "C" int vg_conv5x5_wgrad_bf16split(const float* x, const float* gy, float
   A.Cin = Cin; A.H = H; A.W = W; A.Cout = Cout; A.CoP = p.CoP; A.OH = p.OH; A.OW = p.OW;
   A.mtiles = p.mtiles; A.ntiles = p.ntiles; A.splits = p.splits; A.tiles_w = p.tiles_w; A.tiles_hw = p.tiles_hw;
   A.chunks = p.chunks; A.chunks_per_split = p.cps;
+  A.xcd_aware = 1;
   const long grid = (long)p.mtiles * p.ntiles * p.splits;
   if (grid > 0x7fffffffL) return VG_ERR_BAD_ARG;
   int rc;
