@@ -4,30 +4,48 @@ discriminator, three optimizer steps; experiments/new_betavaegan.py:87-193 of th
 reference) in images/s on N MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 128]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
 
 One process per GPU; per-GPU batch 128 (BASELINE.json configs[1] at N=1; configs[2]
-= global batch 1024 at N=8: weak scaling).  Synthetic data (U(-1,1) images, N(0,1)
-noise) resident in HBM before the timed region; weights from the reference's seed
-recipe.  Prints ONE JSON line on rank 0.
+= global batch 1024 at N=8: weak scaling).  ``--gpus N`` with N > 1 STARTS the N ranks
+itself: before anything touches the GPU this process launches
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
+bench.py --gpus N ...`` as a child, relays rank 0's JSON line and exits with the child's
+status (replaces nn.DataParallel of new_betavaegan.py:42,44).  When the driver has already
+launched the ranks (WORLD_SIZE in the environment) the process is one of them.
+Synthetic data (U(-1,1) images, N(0,1) noise; each rank its own shard) resident in HBM
+before the timed region; weights from the reference's seed recipe.  Prints ONE JSON line
+on rank 0.
+
+``--rehearse-launch``: the same launch path without a GPU -- every rank joins a gloo group,
+the world is checked with an all-reduce and rank 0 prints a line marked "rehearsal" (no
+throughput is measured or reported).  ``VG_DIST_BACKEND=gloo`` runs the real benchmark with
+gloo as the transport (ranks may then share one GPU: a 2-rank rehearsal on a one-GPU box).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak (spec)
-PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (the opt-in bf16x3 mode issues 3 of them per product)
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (spec); bf16x6 issues 6 of them per fp32 multiply, bf16x3 3
 ALG_GFLOP_PER_IMAGE = 20.075       # BASELINE.md section 2 (necessary passes only)
 ALG_CONV_GFLOP_PER_IMAGE = 18.488
+MFMAS_PER_PRODUCT = {"bf16x6": 6, "bf16x3": 3}
+ARITH_NOTE = {
+    "fp32": "exact fp32-input MFMA (v_mfma_f32_32x32x2_f32)",
+    "bf16x6": "fp32-equivalent: every fp32 operand split exactly into 3 bf16 planes (8+8+8 mantissa bits), 6 bf16 "
+              "MFMAs per multiply (all plane pairs whose index sum < 3), fp32 accumulate; conv rel. error vs fp64 "
+              "4e-7..9e-7 (the fp32-input MFMA: 5e-7..1e-6)",
+    "bf16x3": "operands split into 2 bf16 planes (hi/lo), 3 bf16 MFMAs per multiply, fp32 accumulate; 4.5e-6 per "
+              "convolution",
+}
 
 
 def conv_flops(key):
@@ -40,43 +58,104 @@ def conv_flops(key):
     return 2.0 * B * oh * ow * Cin * Cout * 25   # conv_fwd and conv_wgrad
 
 
-def pmc_traffic(dominant):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass
-    (profiles/r01_pmc_dominant_conv_fwd.json: FETCH_SIZE x2 (gfx950 correction, calibrated) +
-    WRITE_SIZE).  Counters cannot be collected from inside this process, so the figure is the
-    profile's; it is reported only when it is for exactly this launch shape."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_dominant_conv_fwd.json")
+def pmc_traffic(dominant, arith):
+    """HBM bytes per launch of the dominant kernel.  Hardware counters cannot be read from inside
+    the process being measured: they come from separate `rocprofv3 --pmc` passes over THIS command
+    (scripts/pmc_bench.sh: FETCH_SIZE x2 -- the gfx950 correction of MI355X_MICROARCH.md section HBM --
+    and WRITE_SIZE, one pass each), whose per-launch averages are committed under profiles/.  The
+    figure is reported only when a committed pass exists for exactly this launch shape and arithmetic."""
+    pdir = os.path.join(ROOT, "profiles")
     try:
-        with open(path) as f:
-            pmc = json.load(f)
+        names = sorted(f for f in os.listdir(pdir) if f.endswith(".json") and "_pmc_" in f)
     except OSError:
         return None, None
-    L = pmc["launch"]
-    key = (L["op"], L["B"], L["Cin"], L["H"], L["W"], L["Cout"], L["stride"])
-    if tuple(dominant) != key:
-        return None, None
-    return pmc["hbm_bytes_per_launch"], "profiles/r01_pmc_dominant_conv_fwd.json"
+    for name in reversed(names):                       # newest round first
+        try:
+            with open(os.path.join(pdir, name)) as f:
+                pmc = json.load(f)
+            L = pmc["launch"]
+            key = (L["op"], L["B"], L["Cin"], L["H"], L["W"], L["Cout"], L["stride"])
+        except (OSError, KeyError, ValueError):
+            continue
+        if tuple(dominant) == key and pmc.get("arith", "fp32") == arith:
+            return pmc["hbm_bytes_per_launch"], "profiles/" + name
+    return None, None
+
+
+def _median_time(fn, warm, timed):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(timed):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return statistics.median(ts), ts
 
 
 def cpu_baseline(batch, beta):
-    """The oracle (CPU restatement of the reference's path) timed on this host's cores on a
-    bounded sample: one iteration at the benchmark's per-GPU batch after a small warm-up."""
+    """The oracle (CPU restatement of the reference's path) timed on this host's cores on a bounded
+    sample (SURVEY.md section 8d protocol): 1 warm-up + 5 timed iterations, median -- the beta-VAE-GAN
+    iteration at the benchmark's per-GPU batch (BASELINE config 2) and the `new_vae` iteration at
+    batch 16 (config 1, the reference's own CPU-runnable case)."""
+    import torch
     from oracle import steps as osteps
     # the GPU box gives one job a 16-core share of the host; more threads only oversubscribe
     threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 16)
     torch.set_num_threads(threads)
     eg, d, oeg, od = osteps.build_nets()
-    wb = osteps.synthetic_batch(8)
-    osteps.betavaegan_step(eg, d, oeg, od, wb["data"], wb["noise"], wb["eps2"], wb["eps3"], beta=beta)
     b = osteps.synthetic_batch(batch)
-    n_it = 2
-    t0 = time.perf_counter()
-    for _ in range(n_it):
-        osteps.betavaegan_step(eg, d, oeg, od, b["data"], b["noise"], b["eps2"], b["eps3"], beta=beta)
-    dt = time.perf_counter() - t0
-    return {"value": round(n_it * batch / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"{n_it} full beta-VAE-GAN iterations at batch {batch} (after a batch-8 warm-up), "
-                      f"torch CPU fp32, {threads} threads, {dt:.2f} s"}
+    med, ts = _median_time(lambda: osteps.betavaegan_step(eg, d, oeg, od, b["data"], b["noise"], b["eps2"], b["eps3"],
+                                                          beta=beta), 1, 5)
+    vae, _, ovae, _ = osteps.build_nets()
+    b16 = osteps.synthetic_batch(16)
+    med_v, ts_v = _median_time(lambda: osteps.vae_step(vae, ovae, b16["data"], b16["eps2"], beta=1.0), 1, 5)
+    return {"value": round(batch / med, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"beta-VAE-GAN iteration at batch {batch}: 1 warm-up + 5 timed iterations, median {med:.3f} s "
+                      f"(min {min(ts):.3f}, max {max(ts):.3f}); torch CPU fp32, {threads} threads",
+            "config1_new_vae_b16": {"value": round(16 / med_v, 2), "unit": "images/s", "s_per_iteration": round(med_v, 4),
+                                    "sample": f"new_vae.py beta=1 VAE iteration at batch 16, 1 warm-up + 5 timed, median "
+                                              f"(min {min(ts_v):.3f} s, max {max(ts_v):.3f} s)"}}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """Start `args.gpus` ranks as children (this process has not touched the GPU and never will),
+    relay their output and return the exit status."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
+def rehearse(args, world, rank):
+    """Launch-path rehearsal on CPU ranks (gloo): proves that N ranks start, rendezvous and agree on
+    the world; measures nothing."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    t = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(t)
+    assert int(t.item()) == world == args.gpus, (t.item(), world, args.gpus)
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "note": "launch path only (gloo, CPU ranks): nothing was measured",
+                          "n_gpus": world, "ranks_counted_by_all_reduce": int(t.item()),
+                          "config": {"parallelism": "dp%d" % world, "global_batch": args.batch * world}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -87,19 +166,32 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--beta", type=float, default=25.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-opt-in", action="store_true", help="skip the informational bf16x3 measurement")
+    ap.add_argument("--no-opt-in", action="store_true", help="skip the informational legs in the other arithmetics")
+    ap.add_argument("--rehearse-launch", action="store_true", help="exercise the N-rank launch on CPU (gloo); no measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))       # nothing above touched the GPU
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.rehearse_launch:
+        return rehearse(args, world, rank)
+
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
         torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))   # (rehearsals: ranks may share a GPU)
         backend = os.environ.get("VG_DIST_BACKEND", "nccl")     # "nccl" IS RCCL on ROCm; gloo only for rehearsals
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
         else:
             dist.init_process_group(backend)
     else:
@@ -110,7 +202,7 @@ def main():
     from disentangle_mlp_amd.trainer import BetaVAEGANTrainer
 
     B = args.batch
-    arith = ops.CONV_ARITH               # "fp32" unless VG_CONV_ARITH=bf16x3 was exported
+    arith = ops.CONV_ARITH               # the product default unless VG_CONV_ARITH was exported
     tr = BetaVAEGANTrainer(device=dev, seed=999, beta=args.beta)
     g = torch.Generator().manual_seed(1234 + rank)            # each rank its own shard
     data = (torch.rand(B, 3, 64, 64, generator=g) * 2 - 1).to(dev)
@@ -125,6 +217,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed_steps(n):
+        """n iterations; wall time of all of them + the per-iteration GPU times between HIP events
+        recorded on the launch stream (no synchronisation inside the loop)."""
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        fence()
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(n):
+            o = one_step()
+            marks[i + 1].record()
+        fence()
+        wall = time.perf_counter() - t0
+        return wall, [marks[i].elapsed_time(marks[i + 1]) for i in range(n)], o
+
     # ---- warm-up; the last warm-up step times every convolution launch to find the dominant one
     for i in range(max(args.warmup, 1)):
         if i == max(args.warmup, 1) - 1:
@@ -136,46 +242,29 @@ def main():
     conv_ms_profiled = sum(totals.values())
 
     # ---- timed region: exactly K steps, dominant kernel bracketed by HIP events
-    fence()
     ops.start_timing(only=dominant)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed, step_ms, out = timed_steps(args.steps)
     dom_ms = ops.stop_timing().get(dominant, [])
 
-    # ---- informational: the same K steps in the two opt-in split-bf16 arithmetics (N = 1 only; NOT `value`)
-    opt_in = None
-    if world == 1 and arith == "fp32" and not args.no_opt_in:
-        opt_in = {}
-        notes = {"bf16x6": ("every fp32 operand split exactly into 3 bf16 planes (8+8+8 mantissa bits), 6 bf16 MFMAs per "
-                            "multiply, fp32 accumulate: fp32-equivalent -- the whole GPU test suite passes at the fp32 "
-                            "tolerances with VG_CONV_ARITH=bf16x6", 8.6e-7),
-                 "bf16x3": ("operands split into 2 bf16 planes (hi/lo), 3 bf16 MFMAs per multiply, fp32 accumulate; "
-                            "tests hold it to 2e-5 per convolution", 4.5e-6)}
+    # ---- informational: the same K steps in the other arithmetics (N = 1 only; NOT `value`)
+    other = None
+    if world == 1 and not args.no_opt_in:
+        other = {}
         try:
-            for mode in ("bf16x6", "bf16x3"):
+            for mode in ("fp32", "bf16x6", "bf16x3"):
+                if mode == arith:
+                    continue
                 ops.CONV_ARITH = mode
                 for _ in range(2):
                     one_step()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    out2 = one_step()
-                torch.cuda.synchronize()
-                e2 = time.perf_counter() - t1
-                opt_in[mode] = {"value": round(B * args.steps / e2, 2), "unit": "images/s",
-                                "ms_per_step": round(e2 / args.steps * 1e3, 3),
-                                "arithmetic": notes[mode][0], "conv_rel_error_vs_fp64": notes[mode][1],
-                                "losses_finite": all(bool(torch.isfinite(v).all()) for v in out2.values())}
+                e2, ms2, out2 = timed_steps(args.steps)
+                other[mode] = {"value": round(B * args.steps / e2, 2), "unit": "images/s",
+                               "ms_per_step": round(e2 / args.steps * 1e3, 3),
+                               "ms_per_step_median": round(statistics.median(ms2), 3), "arithmetic": ARITH_NOTE[mode],
+                               "losses_finite": all(bool(torch.isfinite(v).all()) for v in out2.values())}
         finally:
-            ops.CONV_ARITH = "fp32"
-        opt_in["note"] = ("ops.CONV_ARITH / VG_CONV_ARITH; not the headline: `value` is the exact-fp32-MFMA path "
-                          "(conv rel. error vs fp64 5e-7..1e-6)")
+            ops.CONV_ARITH = arith
+        other["note"] = "ops.CONV_ARITH / VG_CONV_ARITH; informational, not the headline `value`"
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -190,15 +279,20 @@ def main():
         if dominant and dom_ms:
             avg_ms = sum(dom_ms) / len(dom_ms)
             ach = conv_flops(dominant) / (avg_ms * 1e-3) / 1e12
-            traffic, tsrc = pmc_traffic(dominant)
-            x3 = arith != "fp32" and dominant[0] != "conv_wgrad" and dominant[2] % 16 == 0
-            nprod = 6 if arith == "bf16x6" else 3
-            peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None if x3 else traffic, "traffic_unit": "bytes/launch",
-                    "traffic_source": None if x3 else tsrc,
-                    "kernel": ("conv5x5_bf16split_kernel (%d bf16 MFMAs per product: effective peak %.0f)" % (nprod, peak / nprod)) if x3
-                    else ("conv5x5_igemm_kernel" if dominant[0] != "conv_wgrad" else "conv5x5_wgrad_kernel"),
+            traffic, tsrc = pmc_traffic(dominant, arith)
+            split = arith != "fp32" and ops.conv_runs_split(dominant[0], dominant[2])
+            nprod = MFMAS_PER_PRODUCT.get(arith, 1) if split else 1
+            # the roof of the split arithmetics: each fp32 multiply-add costs `nprod` bf16 MFMA multiply-adds,
+            # so the dense bf16 peak / nprod is what a perfect kernel of this arithmetic would reach
+            peak = PEAK_BF16_MFMA_TFLOPS / nprod if split else PEAK_FP32_MFMA_TFLOPS
+            kname = {"conv_fwd": "conv5x5_bf16split_kernel", "convT_fwd": "conv5x5_bf16split_kernel",
+                     "conv_wgrad": "conv5x5_wgrad_bf16split_kernel"}[dominant[0]] if split else \
+                ("conv5x5_igemm_kernel" if dominant[0] != "conv_wgrad" else "conv5x5_wgrad_kernel")
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+                    "traffic_source": tsrc, "kernel": kname,
+                    "peak_note": ("dense bf16 MFMA 2500 TFLOP/s / %d MFMAs per fp32 multiply" % nprod) if split
+                    else "fp32-input MFMA = fp32 vector peak",
                     "launch": {"op": dominant[0], "B": dominant[1], "Cin": dominant[2], "H": dominant[3],
                                "W": dominant[4], "Cout": dominant[5], "stride": dominant[6]},
                     "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(dom_ms),
@@ -206,23 +300,27 @@ def main():
         res = {
             "metric": "celeba64_betavaegan_train_images_per_sec", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "ms_per_step_median": round(statistics.median(step_ms), 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp32" if arith == "fp32" else arith + " (convolutions: split-bf16 operands on the bf16 MFMA, "
-                                                    "fp32 accumulate) + fp32 (3-channel layers, everything else)",
+            "dtype": "fp32" if arith == "fp32" else
+                     "fp32-equivalent (%s split of fp32 operands on the bf16 MFMA, fp32 accumulate; 3-channel layers and "
+                     "everything else fp32)" % arith if arith == "bf16x6" else
+                     arith + " (split-bf16 operands on the bf16 MFMA, fp32 accumulate) + fp32 elsewhere",
+            "arithmetic": ARITH_NOTE[arith],
             "data": "synthetic",
             "config": {"workload": "new_betavaegan.py beta=25 VAE-GAN iteration (D + decoder + encoder phases, "
                                    "3 Adam steps), CelebA 64x64, per-GPU batch %d" % B,
                        "global_batch": B * world, "per_gpu_batch": B, "beta": args.beta,
                        "parallelism": "dp%d" % world},
             "roofline": roof,
-            "step_tflops_algorithmic": round(ALG_GFLOP_PER_IMAGE * value / 1e3, 2),
+            "step_tflops_algorithmic": round(ALG_GFLOP_PER_IMAGE * value / world / 1e3, 2),
             "conv_path_frac_of_fp32_mfma_peak": round(ALG_CONV_GFLOP_PER_IMAGE * value / world / 1e3
                                                       / PEAK_FP32_MFMA_TFLOPS, 4),
             "conv_ms_per_step_profiled": round(conv_ms_profiled, 3),
             "losses_finite": finite,
         }
-        if world == 1 and arith == "fp32" and not args.no_opt_in:
-            res["opt_in"] = opt_in
+        if other is not None:
+            res["other_arithmetics"] = other
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(B, args.beta)
         print(json.dumps(res), flush=True)

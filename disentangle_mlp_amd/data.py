@@ -78,11 +78,16 @@ def build_image_cache(root, img_size, cache_dir=None, workers=None):
                 return img_file, lab_file
     os.makedirs(cache_dir, exist_ok=True)
     n = len(samples)
-    out = np.lib.format.open_memmap(img_file + ".tmp", mode="w+", dtype=np.uint8, shape=(n, img_size, img_size, 3))
+    # temporaries are private to this process (two builders never map the same file) and every final
+    # name appears by an atomic rename; the meta file is written last and marks the cache as valid
+    tmp = f".tmp{os.getpid()}"
+    out = np.lib.format.open_memmap(img_file + tmp, mode="w+", dtype=np.uint8, shape=(n, img_size, img_size, 3))
     jobs = [(p, img_size) for p, _ in samples]
     workers = workers if workers is not None else min(16, os.cpu_count() or 1)
     if workers > 1 and n >= 256:
-        with ProcessPoolExecutor(max_workers=workers) as pool:
+        import multiprocessing
+        # "spawn": the parent may already hold a GPU context, which a forked child must not inherit
+        with ProcessPoolExecutor(max_workers=workers, mp_context=multiprocessing.get_context("spawn")) as pool:
             for i, arr in enumerate(pool.map(_decode_resized, jobs, chunksize=64)):
                 out[i] = arr
     else:
@@ -90,10 +95,13 @@ def build_image_cache(root, img_size, cache_dir=None, workers=None):
             out[i] = _decode_resized(job)
     out.flush()
     del out
-    os.replace(img_file + ".tmp", img_file)
-    np.save(lab_file, np.asarray([ci for _, ci in samples], dtype=np.int64))
-    with open(meta_file, "w") as f:
+    os.replace(img_file + tmp, img_file)
+    with open(lab_file + tmp, "wb") as f:
+        np.save(f, np.asarray([ci for _, ci in samples], dtype=np.int64))
+    os.replace(lab_file + tmp, lab_file)
+    with open(meta_file + tmp, "w") as f:
         json.dump({"fingerprint": fp, "n": n, "img_size": img_size, "classes": classes}, f)
+    os.replace(meta_file + tmp, meta_file)
     return img_file, lab_file
 
 
@@ -145,6 +153,9 @@ class DeviceLoader:
             raise ValueError("batch_size must be a positive multiple of world_size")
         self.dataset, self.batch_size, self.shuffle = dataset, int(batch_size), bool(shuffle)
         self.rank, self.world_size, self.generator = int(rank), int(world_size), generator
+        # images of the GLOBAL batch the last yielded shard belongs to: the divisor of a batch-mean
+        # loss under data parallelism (a short last batch is split unevenly over the ranks)
+        self.last_global_batch = None
 
     def __len__(self):
         return math.ceil(len(self.dataset) / self.batch_size)
@@ -173,7 +184,10 @@ class DeviceLoader:
                 per = local if chunk.numel() == gb else math.ceil(chunk.numel() / self.world_size)
                 if per * (self.world_size - 1) >= chunk.numel():
                     break       # a tail too short to give every rank a sample: dropped on ALL ranks (collectives stay matched)
+                self.last_global_batch = chunk.numel()
                 chunk = chunk[self.rank * per:(self.rank + 1) * per]
+            else:
+                self.last_global_batch = chunk.numel()
             yield chunk
 
     def __iter__(self):
@@ -200,10 +214,21 @@ def get_data_loader(opt):
     cache_dir = getattr(opt, "cache_dir", None)
     workers = getattr(opt, "num_workers", None) or None
     rank, world = _dist_info()
+    splits = (("train", True), ("val", False), ("test", False))
+    # All three caches are built before the first upload touches the device, by rank 0 only; the
+    # other ranks wait at the barrier and then find the finished caches (their build is a lookup).
+    files = {}
+    if rank == 0:
+        for split, _ in splits:
+            files[split] = build_image_cache(getattr(opt, f"image_root_{split}"), opt.img_size, cache_dir, workers)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
     loaders = []
-    for split, shuffle in (("train", True), ("val", False), ("test", False)):
-        root = getattr(opt, f"image_root_{split}")
-        img_file, lab_file = build_image_cache(root, opt.img_size, cache_dir, workers)
+    for split, shuffle in splits:
+        if split not in files:
+            files[split] = build_image_cache(getattr(opt, f"image_root_{split}"), opt.img_size, cache_dir, workers)
+        img_file, lab_file = files[split]
         ds = DeviceImageDataset.from_files(img_file, lab_file, device=device, mean=0.5, std=0.5)
         loaders.append(DeviceLoader(ds, getattr(opt, f"batch_size_{split}"), shuffle=shuffle,
                                     rank=rank if split == "train" else 0,

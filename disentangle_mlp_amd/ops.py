@@ -76,9 +76,10 @@ def _ptr(t):
 
 
 def workspace(nbytes, device):
-    """Per-device scratch, grown on demand; all kernels of a step run on one stream,
-    so one buffer serves every two-stage reduction / split-K slab in turn."""
-    key = (device.type, device.index)
+    """Scratch per (device, stream), grown on demand: kernels launched on one stream are ordered, so
+    one buffer serves every two-stage reduction / split-K slab of that stream in turn; work on
+    another stream (a side stream, a second trainer thread) gets its own."""
+    key = (device.type, device.index, _stream())
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         nbytes = max(int(nbytes), 1 << 20)
@@ -114,6 +115,20 @@ if CONV_ARITH not in ("fp32", "bf16x3", "bf16x6"):
 def _planes():
     """bf16 operand planes of the active arithmetic: 0 (exact fp32 MFMA), 2 (bf16x3) or 3 (bf16x6)."""
     return {"fp32": 0, "bf16x3": 2, "bf16x6": 3}[CONV_ARITH]
+
+
+def conv_runs_split(op, cin, cout=None, stride=None):
+    """Whether a convolution launch of kind ``op`` ("conv_fwd" | "convT_fwd" | "conv_wgrad") with
+    ``cin`` input channels runs on the split-bf16 kernels under the active arithmetic (bench.py:
+    which roofline a launch is priced against).  Mirrors the dispatch conditions below."""
+    planes = _planes()
+    if not planes:
+        return False
+    if op == "conv_wgrad":
+        return WGRAD_SPLIT and cin >= (16 if planes == 2 else 32)
+    if op == "convT_fwd" and stride == 1 and cout is not None and cout <= 4:
+        return False
+    return cin % 16 == 0
 
 
 _pack_scope_depth = 0

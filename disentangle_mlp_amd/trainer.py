@@ -24,6 +24,7 @@ gradient.
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
+import numpy as np
 import torch
 import torch.distributed as dist
 from torch import optim
@@ -168,6 +169,41 @@ def _dist_world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _dist_rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def _latent_generator(device, seed, rank):
+    """Generator of the latent draws this replica makes itself (``noise`` of new_betavaegan.py:111,
+    ``eps`` of model.py:534).  Weights come from ``torch.manual_seed(seed)`` on every rank (replicas
+    start identical, and the CPU generator stays shared: the loader's permutation must agree on all
+    ranks); the latents must NOT: the reference draws one independent sample per image of the global
+    batch, so each rank seeds its own stream with seed + 1 + rank."""
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed) + 1 + int(rank))
+    return g
+
+
+def sample_labels(rng=None):
+    """The per-iteration label draw of new_betavaegan.py:89-90 (new_gan.py:68-69 alike): soft labels
+    0.9 / 0.1, each flipped with probability 5 %.  Draw order as in the reference -- the fake label
+    first, then the real one -- from ``rng.choice`` (default: NumPy's global ``np.random``, the stream
+    the reference consumes; pass a ``np.random.RandomState`` for a reproducible run).
+    Returns (real_label, fake_label) as Python floats."""
+    rng = np.random if rng is None else rng
+    fake_label = rng.choice(a=[0.1, 0.9], p=[0.95, 0.05])
+    real_label = rng.choice(a=[0.1, 0.9], p=[0.05, 0.95])
+    return float(real_label), float(fake_label)
+
+
+def _loader_global_batch(loader, local_batch, world):
+    """Images of the current GLOBAL batch: what nn.BCELoss's mean runs over under the reference's
+    DataParallel.  data.DeviceLoader publishes it (a short last batch is split unevenly over the
+    ranks); for a foreign loader every rank is assumed to hold an equal share."""
+    gb = getattr(loader, "last_global_batch", None)
+    return int(gb) if gb else int(local_batch) * world
+
+
 class BetaVAEGANTrainer:
     """One replica of the beta-VAE-GAN (new_betavaegan.py:36-53 construction recipe)."""
 
@@ -195,6 +231,12 @@ class BetaVAEGANTrainer:
         self.iteration = 0
         self._eg_params = [p for p in self.netEG.parameters() if p.dim() == 4]   # convolution filters
         self._d_params = [p for p in self.netD.parameters() if p.dim() == 4]
+        self.rank = _dist_rank()
+        self.latent_generator = _latent_generator(self.device, seed, self.rank)
+
+    def draw_latents(self, batch):
+        """One N(0,1) draw of shape (batch, n_hidden) from this replica's own stream."""
+        return torch.randn(batch, self.opt.n_hidden, device=self.device, generator=self.latent_generator)
 
     # -- gradient plumbing ------------------------------------------------------
     def _zero(self, net, flat):
@@ -225,13 +267,14 @@ class BetaVAEGANTrainer:
         ``grad_hook(phase, net)`` (tests) is called right before each optimizer step."""
         netEG, netD = self.netEG, self.netD
         B = data.size(0)
-        nh = self.opt.n_hidden
         if noise is None:
-            noise = torch.randn(B, nh, device=data.device)
+            noise = self.draw_latents(B)
         if eps2 is None:
-            eps2 = torch.randn(B, nh, device=data.device)
+            eps2 = self.draw_latents(B)
         if eps3 is None:
-            eps3 = torch.randn(B, nh, device=data.device)
+            eps3 = self.draw_latents(B)
+        # BCE is a mean over the GLOBAL batch (DataParallel gathers the outputs before the loss); equal
+        # shards are assumed unless the caller says otherwise (train_epoch passes the loader's count)
         gb = global_batch if global_batch is not None else B * self.world
         out = {}
 
@@ -287,6 +330,37 @@ class BetaVAEGANTrainer:
         self.iteration += 1
         return out
 
+    # -- one epoch (new_betavaegan.py:77-201) ---------------------------------------------
+    def train_epoch(self, loader, label_rng=None, max_iterations=None):
+        """``train(epoch)`` of new_betavaegan.py:77-201 over ``for data, _ in loader``: per iteration
+        the label draw of :89-90 (`sample_labels`) and one `step`; returns the reference's tuple
+        ``(avg_recon_enc_loss, avg_recon_dec_loss, avg_dis_loss, avg_Dx)`` of :196-201.
+
+        The reference's bookkeeping is kept as it is: both
+        reconstruction averages accumulate the *encoder-phase* pixel MSE (:188-189 add the same
+        ``loss``), ``avg_dis_loss`` and ``avg_Dx`` both accumulate the batch mean of D(x) (:105-107,
+        :190), and all four sums -- per-batch sums of squared errors, and per-batch *means* of D(x) --
+        are divided by ``len(loader.dataset)``.  The sums live on the device; the host reads them once
+        per epoch (the reference synchronises four times per iteration with ``.item()``).
+        Under data parallelism the sums are all-reduced once at the end, so every rank returns the
+        global-batch values the reference's DataParallel run would log."""
+        acc = torch.zeros(2, dtype=torch.float64, device=self.device)     # [sum of mse_enc, sum of mean D(x)]
+        n_it = 0
+        for data, _ in loader:
+            real_label, fake_label = sample_labels(label_rng)
+            gb = _loader_global_batch(loader, data.size(0), self.world)
+            out = self.step(data, real_label=real_label, fake_label=fake_label, global_batch=gb)
+            acc[0] += out["mse_enc"]
+            acc[1] += out["D_x_sum"] / gb
+            n_it += 1
+            if max_iterations is not None and n_it >= max_iterations:
+                break
+        if self.world > 1:
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        mse_sum, dx_sum = acc.tolist()                                    # the epoch's one device -> host read
+        n = len(loader.dataset)
+        return mse_sum / n, mse_sum / n, dx_sum / n, dx_sum / n
+
     # -- checkpoint (new_betavaegan.py:203-209, 222-228) --------------------------------
     def checkpoint(self, epoch):
         """The reference's dict.  ``discriminator_model`` keys carry the ``module.`` prefix
@@ -331,6 +405,7 @@ class VAETrainer:
         self.optimizer = _make_adam(self.model.parameters(), lr, fused_adam and self.device.type == "cuda", capturable)
         self.world = _dist_world()
         self.flat = FlatGrads(self.model.parameters()) if self.world > 1 else None
+        self.latent_generator = _latent_generator(self.device, seed, _dist_rank())
         self.model.train()
 
     def step(self, data, eps=None):
@@ -338,6 +413,8 @@ class VAETrainer:
             return self._step(data, eps)
 
     def _step(self, data, eps):
+        if eps is None:                       # model.py:534, from this replica's own stream
+            eps = torch.randn(data.size(0), self.opt.n_hidden, device=self.device, generator=self.latent_generator)
         if self.flat is not None:
             self.flat.zero_and_attach()
         else:
@@ -350,14 +427,32 @@ class VAETrainer:
         self.optimizer.step()
         return dict(mse=mse.detach(), kld=kld.detach())
 
+    def train_epoch(self, loader, max_iterations=None):
+        """``train(epoch)`` of new_vae.py:48-68: returns ``avg_loss`` = sum over the epoch of
+        (MSE + KLD) / len(dataset); one device -> host read per epoch."""
+        acc = torch.zeros((), dtype=torch.float64, device=self.device)
+        n_it = 0
+        for data, _ in loader:
+            out = self.step(data)
+            acc += out["mse"] + out["kld"]
+            n_it += 1
+            if max_iterations is not None and n_it >= max_iterations:
+                break
+        if self.world > 1:
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        return float(acc.item()) / len(loader.dataset)
+
     def checkpoint(self, epoch):
         return {"epoch": epoch, "VAE_model": self.model.state_dict(), "optimizer": self.optimizer.state_dict()}
 
 
 class GANTrainer:
-    """new_gan.py:47-61 construction, :66-141 step."""
+    """new_gan.py:47-61 construction, :66-141 step.  Data parallel like the beta-VAE-GAN driver (the
+    reference wraps both nets in nn.DataParallel, new_gan.py:51-53): replica-local BatchNorm, one
+    gradient exchange (SUM) per optimizer step, BCE divided by the global batch."""
 
-    def __init__(self, device="cuda", seed=999, lr=3e-3, opt: Optional[ModelOpt] = None, fused_adam: bool = True):
+    def __init__(self, device="cuda", seed=999, lr=3e-3, opt: Optional[ModelOpt] = None, fused_adam: bool = True,
+                 data_parallel: Optional[bool] = None):
         self.opt = opt or ModelOpt()
         self.device = torch.device(device)
         torch.manual_seed(seed)
@@ -369,37 +464,85 @@ class GANTrainer:
         fused = fused_adam and self.device.type == "cuda"
         self.optimizerG = _make_adam(self.netG.parameters(), lr, fused)
         self.optimizerD = _make_adam(self.netD.parameters(), lr, fused)
+        self.world = _dist_world()
+        self.dp = (self.world > 1) if data_parallel is None else data_parallel
+        self.flat_g = FlatGrads(self.netG.parameters()) if self.dp else None
+        self.flat_d = FlatGrads(self.netD.parameters()) if self.dp else None
+        self.latent_generator = _latent_generator(self.device, seed, _dist_rank())
         self.netG.train()
         self.netD.train()
 
-    def step(self, data, noise=None, real_label=0.9, fake_label=0.1):
-        with ops.packed_filter_scope():
-            return self._step(data, noise, real_label, fake_label)
+    def _zero(self, net, flat):
+        if flat is not None:
+            flat.zero_and_attach()
+        else:
+            net.zero_grad(set_to_none=True)
 
-    def _step(self, data, noise, real_label, fake_label):
+    def _exchange(self, flat):
+        if flat is not None and (self.world > 1 or FlatGrads.exchange_when_alone):
+            flat.finish()
+
+    def step(self, data, noise=None, real_label=0.9, fake_label=0.1, global_batch: Optional[int] = None,
+             grad_hook=None):
+        with ops.packed_filter_scope():
+            return self._step(data, noise, real_label, fake_label, global_batch, grad_hook)
+
+    def _step(self, data, noise, real_label, fake_label, global_batch, grad_hook):
         B = data.size(0)
         if noise is None:
-            noise = torch.randn(B, self.opt.n_hidden, device=data.device)
-        self.netD.zero_grad(set_to_none=True)
+            noise = torch.randn(B, self.opt.n_hidden, device=self.device, generator=self.latent_generator)
+        gb = global_batch if global_batch is not None else B * self.world
+        self._zero(self.netD, self.flat_d)
         p_real, _ = self.netD(data)
-        err_real = F.bce_loss(p_real, real_label)
+        err_real = F.bce_loss(p_real, real_label, gb)
         fake = self.netG(noise)
         p_fake, _ = self.netD(fake.detach())
-        err_fake = F.bce_loss(p_fake, fake_label)
+        err_fake = F.bce_loss(p_fake, fake_label, gb)
         torch.autograd.backward([err_real, err_fake])
+        self._exchange(self.flat_d)
+        if grad_hook:
+            grad_hook("D", self.netD)
         self.optimizerD.step()
         ops.invalidate_packed_filters()
-        self.netG.zero_grad(set_to_none=True)
+        self._zero(self.netG, self.flat_g)
         for p in self.netD.parameters():
             p.requires_grad_(False)
         p_fake2, _ = self.netD(fake)
-        err_g = F.bce_loss(p_fake2, real_label)
+        err_g = F.bce_loss(p_fake2, real_label, gb)
         err_g.backward()
         for p in self.netD.parameters():
             p.requires_grad_(True)
+        self._exchange(self.flat_g)
+        if grad_hook:
+            grad_hook("G", self.netG)
         self.optimizerG.step()
         return dict(errD_real=err_real.detach(), errD_fake=err_fake.detach(), errG=err_g.detach(),
                     D_x_sum=p_real.detach().sum())
+
+    def train_epoch(self, loader, label_rng=None, max_iterations=None):
+        """``train()`` of new_gan.py:66-141: label draw per iteration (:68-69), returns the reference's
+        ``(avg_loss_G, avg_loss_D)`` -- including its bookkeeping: ``avg_loss_G`` is the sum of the
+        per-batch generator losses over ``len(dataset)``, and the second value is *that average* divided
+        by ``len(dataset)`` once more (new_gan.py:138 reads ``avg_loss_G`` where ``avg_loss_D`` was
+        meant).  The sum of errD over the epoch is available as ``self.last_epoch_sums["errD"]``."""
+        acc = torch.zeros(2, dtype=torch.float64, device=self.device)
+        n_it = 0
+        for data, _ in loader:
+            real_label, fake_label = sample_labels(label_rng)
+            gb = _loader_global_batch(loader, data.size(0), self.world)
+            out = self.step(data, real_label=real_label, fake_label=fake_label, global_batch=gb)
+            acc[0] += out["errG"]
+            acc[1] += out["errD_real"] + out["errD_fake"]
+            n_it += 1
+            if max_iterations is not None and n_it >= max_iterations:
+                break
+        if self.world > 1:                       # local BCE terms are already divided by the global batch
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        g_sum, d_sum = acc.tolist()
+        n = len(loader.dataset)
+        self.last_epoch_sums = {"errG": g_sum, "errD": d_sum}
+        avg_loss_g = g_sum / n
+        return avg_loss_g, avg_loss_g / n
 
     def checkpoint(self, epoch):
         return {"epoch": epoch, "netG": self.netG.state_dict(), "netD": self.netD.state_dict(),

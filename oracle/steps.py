@@ -155,23 +155,31 @@ def vae_step(model: VAE, optimizer, data, eps, beta=1.0) -> Dict[str, float]:
 
 
 def gan_step(net_g: Generator_celeba, net_d: Discriminator_celeba, opt_g, opt_d,
-             data, noise, real_label=0.9, fake_label=0.1) -> Dict[str, float]:
-    """new_gan.py:66-141: D(real)+D(fake.detach()) -> step D; D(fake) -> step G."""
+             data, noise, real_label=0.9, fake_label=0.1,
+             bce_divisor: Optional[int] = None, grad_hook=None) -> Dict[str, float]:
+    """new_gan.py:66-141: D(real)+D(fake.detach()) -> step D; D(fake) -> step G.
+    ``bce_divisor`` / ``grad_hook``: as in `betavaegan_step` (N-replica emulation of the
+    reference's nn.DataParallel run, new_gan.py:51-53)."""
     net_g.train()
     net_d.train()
+    scale = 1.0 if bce_divisor is None else data.size(0) / float(bce_divisor)
     net_d.zero_grad()
     p_real, _ = net_d(data)
-    err_real = bce_loss(p_real, real_label)
+    err_real = bce_loss(p_real, real_label) * scale
     err_real.backward()
     fake = net_g(noise)
     p_fake, _ = net_d(fake.detach())
-    err_fake = bce_loss(p_fake, fake_label)
+    err_fake = bce_loss(p_fake, fake_label) * scale
     err_fake.backward()
+    if grad_hook:
+        grad_hook("D", net_d)
     opt_d.step()
     net_g.zero_grad()
     p_fake2, _ = net_d(fake)
-    err_g = bce_loss(p_fake2, real_label)
+    err_g = bce_loss(p_fake2, real_label) * scale
     err_g.backward()
+    if grad_hook:
+        grad_hook("G", net_g)
     opt_g.step()
     return dict(errD_real=err_real.item(), errD_fake=err_fake.item(), errG=err_g.item(),
                 D_x=p_real.mean().item())

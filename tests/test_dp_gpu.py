@@ -130,3 +130,93 @@ def test_rccl_path_in_a_group_of_one():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "rccl-one-rank ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def _gan_worker(rank, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+        torch.cuda.set_device(0)
+        import oracle
+        from oracle import steps as osteps
+        from disentangle_mlp_amd.trainer import GANTrainer
+        batch = 16
+        b = osteps.synthetic_batch(batch)
+        lo, hi = rank * batch // WORLD, (rank + 1) * batch // WORLD
+        tr = GANTrainer(lr=0.0)
+        assert tr.dp and tr.flat_g is not None and tr.flat_d is not None
+        got = {}
+        tr.step(b["data"][lo:hi].cuda(), b["noise"][lo:hi].cuda(),
+                grad_hook=lambda ph, net: got.__setitem__(
+                    ph, {k: p.grad.detach().cpu().double() for k, p in net.named_parameters()}))
+        torch.cuda.synchronize()
+        worst = (0.0, "")
+        if rank == 0:
+            torch.set_num_threads(8)
+            ref = {}
+            for r in range(WORLD):
+                torch.manual_seed(999)
+                ng, nd = oracle.Generator_celeba(oracle.OracleOpt()), oracle.Discriminator_celeba(oracle.OracleOpt())
+                ng.apply(oracle.weights_init), nd.apply(oracle.weights_init)
+                ng, nd = ng.double(), nd.double()
+                og, od = torch.optim.Adam(ng.parameters(), lr=0.0), torch.optim.Adam(nd.parameters(), lr=0.0)
+                bb = osteps.synthetic_batch(batch, dtype=torch.float64)
+                l, h = r * batch // WORLD, (r + 1) * batch // WORLD
+
+                def hook(ph, net):
+                    for k, p in net.named_parameters():
+                        ref.setdefault(ph, {})
+                        ref[ph][k] = ref[ph].get(k, 0) + p.grad.detach().clone()
+                osteps.gan_step(ng, nd, og, od, bb["data"][l:h], bb["noise"][l:h], bce_divisor=batch, grad_hook=hook)
+            for ph, key in (("D", "d"), ("G", "g")):
+                for k, r_ in ref[ph].items():
+                    if k in BN_SHADOWED[key] or float(r_.norm()) == 0.0:
+                        continue
+                    worst = max(worst, (float((got[ph][k] - r_).norm() / r_.norm()), f"{ph}/{k}"))
+        dist.barrier()
+        if rank == 0:
+            q.put(("ok", worst))
+        dist.destroy_process_group()
+    except Exception as exc:
+        q.put(("error", repr(exc)))
+        raise
+
+
+def test_two_rank_gan_step_matches_two_replica_oracle():
+    """new_gan.py:51-53 wraps both networks in nn.DataParallel: GANTrainer exchanges the gradients of D and of G
+    (one all-reduce SUM per optimizer step, BCE over the global batch); rank 0's exchanged gradients vs the
+    oracle's 2-replica emulation."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gan_worker, args=(r, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    status, worst = q.get(timeout=600)
+    for p in procs:
+        p.join(120)
+    assert status == "ok", (status, worst)
+    assert all(p.exitcode == 0 for p in procs)
+    assert worst[0] <= 1e-2, worst
+
+
+def test_bench_launches_two_ranks_on_this_gpu():
+    """`python bench.py --gpus 2` starts its two ranks itself (no torchrun around it) and reports the whole-job
+    rate: here both ranks share the one GPU of the box with gloo as the transport (a one-GPU box cannot host two
+    RCCL ranks), per-GPU batch 16, 2 timed steps."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(VG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--batch", "16", "--no-cpu-baseline", "--no-opt-in"], env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2" and res["config"]["global_batch"] == 32
+    assert res["steps"] == 2 and res["losses_finite"] and res["value"] > 0
+    assert abs(res["value"] - 32 * 2 / (res["ms_per_step"] * 2e-3)) <= 0.01 * res["value"]     # whole-job images/s

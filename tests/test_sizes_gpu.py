@@ -54,3 +54,158 @@ def test_other_resolution_forward_and_gradients(zh, zw, batch):
                 continue
             e = float((got_g[ph][k].double() - r.double()).norm() / r.double().norm())
             assert e <= (5e-3 if ph == "D" else 1e-2), (ph, k, e)   # conftest.GRADNORM_TOL: ReLU units flipping at B <= 4
+
+
+# ---------------------------------------------------------------- BASELINE config 4: new_gan.py at 128x128
+def test_config4_gan_step_128_vs_oracle():
+    """GANTrainer with n_z = [256,16,16] (128x128 images; BASELINE config 4 runs it at batch 256) against
+    `oracle.gan_step` (new_gan.py:66-141) at B=4: one real iteration (losses 1e-4: phase 1 is pre-Adam, errG
+    follows D's first step) and one lr=0 iteration whose gradients of both networks are compared tensor by
+    tensor (5e-3 D, 1e-2 G).  No reference oracle exists beyond 64x64: parity is against the oracle's
+    restatement under the same size rule (model.py:461,558-564 generalised)."""
+    from disentangle_mlp_amd import trainer as T
+    from conftest import BN_SHADOWED
+    import oracle
+    batch, zh = 4, 16
+    oopt = om.OracleOpt(n_z=[256, zh, zh])
+    g = torch.Generator().manual_seed(78)
+    data = torch.rand(batch, 3, 8 * zh, 8 * zh, generator=g) * 2 - 1
+    noise = torch.randn(batch, 128, generator=g)
+
+    def oracle_nets(lr):
+        torch.manual_seed(999)
+        ng, nd = oracle.Generator_celeba(oopt), oracle.Discriminator_celeba(oopt)
+        ng.apply(oracle.weights_init), nd.apply(oracle.weights_init)
+        return ng, nd, torch.optim.Adam(ng.parameters(), lr=lr), torch.optim.Adam(nd.parameters(), lr=lr)
+    # (a) a real iteration
+    ng, nd, og, od = oracle_nets(3e-3)
+    ref = osteps.gan_step(ng, nd, og, od, data, noise)
+    tr = T.GANTrainer(lr=3e-3, opt=T.ModelOpt(n_z=[256, zh, zh]))
+    out = tr.step(data.cuda(), noise.cuda())
+    assert tuple(tr.netG(noise.cuda()).shape) == (batch, 3, 128, 128)
+    for k in ("errD_real", "errD_fake"):
+        assert _close(float(out[k]), ref[k], 2e-5), (k, float(out[k]), ref[k])
+    assert _close(float(out["errG"]), ref["errG"], 1e-3), (float(out["errG"]), ref["errG"])
+    assert _close(float(out["D_x_sum"]) / batch, ref["D_x"], 2e-5)
+    # (b) gradients at the initial weights (lr = 0)
+    ng, nd, og, od = oracle_nets(0.0)
+    ref_g, got_g = {}, {}
+    osteps.gan_step(ng, nd, og, od, data, noise,
+                    grad_hook=lambda ph, net: ref_g.__setitem__(ph, {k: q.grad.clone() for k, q in net.named_parameters()}))
+    tr = T.GANTrainer(lr=0.0, opt=T.ModelOpt(n_z=[256, zh, zh]))
+    tr.step(data.cuda(), noise.cuda(),
+            grad_hook=lambda ph, net: got_g.__setitem__(ph, {k: q.grad.detach().cpu().clone() for k, q in net.named_parameters()}))
+    for ph, key, tol in (("D", "d", 5e-3), ("G", "g", 1e-2)):
+        for k, r in ref_g[ph].items():
+            if k in BN_SHADOWED[key] or float(r.norm()) == 0.0:
+                continue
+            e = float((got_g[ph][k].double() - r.double()).norm() / r.double().norm())
+            assert e <= tol, (ph, k, e)
+
+
+# ---------------------------------------------------------------- BASELINE config 5: beta-VAE-GAN at 256x256
+def test_config5_betavaegan_256_forward_and_gradients():
+    """n_z = [256,32,32] (256x256 images, the two encoder heads and D's feature layer become 262144 -> 2048):
+    forward of both networks (2e-5) and one lr=0 iteration (losses 2e-4, gradients 5e-3 / 1e-2) vs the oracle at
+    B=2, beta = 75 (BASELINE config 5).  Oracle in fp32 (its three 262144x2048 weights are 2 GB each)."""
+    from disentangle_mlp_amd import trainer as T
+    from conftest import BN_SHADOWED
+    batch, zh = 2, 32
+    torch.set_num_threads(16)
+    oopt = om.OracleOpt(n_z=[256, zh, zh])
+    eg, d, oeg, od = osteps.build_nets(opt=oopt)
+    for o in (oeg, od):
+        o.param_groups[0]["lr"] = 0.0
+    tr = T.BetaVAEGANTrainer(beta=75.0, lr=0.0, opt=T.ModelOpt(n_z=[256, zh, zh]))
+    g = torch.Generator().manual_seed(79)
+    data = torch.rand(batch, 3, 8 * zh, 8 * zh, generator=g) * 2 - 1
+    eps2, noise, eps3 = (torch.randn(batch, 128, generator=g) for _ in range(3))
+    with torch.no_grad():
+        recon, mu, lv = tr.netEG(data.cuda(), eps2.cuda())
+        p, feat = tr.netD(data.cuda())
+        r_recon, r_mu, r_lv = eg(data, eps2)
+        r_p, r_feat = d(data)
+    assert tuple(recon.shape) == (batch, 3, 256, 256)
+    for a, b in ((recon, r_recon), (mu, r_mu), (lv, r_lv), (p, r_p), (feat, r_feat)):
+        e = float((a.cpu().double() - b.double()).norm() / b.double().norm())
+        assert e <= 2e-5, e
+    ref_g, got_g = {}, {}
+    ref_l = osteps.betavaegan_step(eg, d, oeg, od, data, noise, eps2, eps3, beta=75.0,
+                                   grad_hook=lambda ph, net: ref_g.__setitem__(ph, {k: q.grad.clone() for k, q in net.named_parameters()}))
+    out = tr.step(data.cuda(), noise.cuda(), eps2.cuda(), eps3.cuda(),
+                  grad_hook=lambda ph, net: got_g.__setitem__(ph, {k: q.grad.detach().cpu().clone() for k, q in net.named_parameters()}))
+    for k, v in ref_l.items():
+        if k in out:
+            assert _close(float(out[k]), v, 2e-4, 1e-6), (k, float(out[k]), v)
+    for ph in ("D", "EG2", "EG3"):
+        skip = set(BN_SHADOWED["d" if ph == "D" else "eg"])
+        for k, r in ref_g[ph].items():
+            if k in skip or float(r.norm()) == 0.0:
+                continue
+            e = float((got_g[ph][k].double() - r.double()).norm() / r.double().norm())
+            assert e <= (5e-3 if ph == "D" else 1e-2), (ph, k, e)
+
+
+# ---------------------------------------------------------------- full-size properties at the config 4 / 5 shapes
+def _dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+# (B, Cin, Cout, H, stride): discriminator / encoder convolutions at 128x128 with batch 256 (config 4) and at
+# 256x256 with the per-GPU batch 64 of config 5 (512 / 8)
+BIG_CONVS = [(256, 3, 32, 128, 1), (256, 32, 128, 128, 2), (256, 128, 256, 64, 2), (256, 256, 256, 32, 2),
+             (64, 3, 64, 256, 2), (64, 32, 128, 256, 2), (64, 128, 256, 128, 2), (64, 256, 256, 64, 2)]
+# decoder transposed convolutions: input (B, Cin, H, H) -> (B, Cout, s*H, s*H)
+BIG_CONVTS = [(256, 256, 256, 16, 2), (256, 256, 128, 32, 2), (256, 128, 32, 64, 2), (256, 32, 3, 128, 1),
+              (64, 256, 256, 32, 2), (64, 128, 32, 128, 2), (64, 32, 3, 256, 1)]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,Hs,stride", BIG_CONVS)
+def test_config45_conv_adjoints_and_linearity(B, Cin, Cout, Hs, stride):
+    """<conv(x,w), g> == <x, dgrad(g,w)> == <w, wgrad(x,g)> and linearity in x at the launch shapes of BASELINE
+    configs 4 and 5 (sizes no CPU oracle finishes in seconds)."""
+    from disentangle_mlp_amd import ops as H
+    gen = torch.Generator(device="cuda").manual_seed(60)
+    x = torch.randn(B, Cin, Hs, Hs, device="cuda", generator=gen)
+    w = 0.05 * torch.randn(Cout, Cin, 5, 5, device="cuda", generator=gen)
+    y = H.conv5x5_fwd(x, w, None, stride)
+    g = torch.randn(y.shape, device="cuda", generator=gen)
+    s_fwd = _dot(y, g)
+    s_dgrad = _dot(x, H.convT5x5_fwd(g, w, None, stride))
+    s_wgrad = _dot(w, H.conv5x5_wgrad(x, g, stride))
+    scale = float(y.double().norm() * g.double().norm())
+    assert abs(s_fwd - s_dgrad) <= 2e-6 * scale, (s_fwd, s_dgrad, scale)
+    assert abs(s_fwd - s_wgrad) <= 2e-6 * scale, (s_fwd, s_wgrad, scale)
+    x2 = torch.randn(x.shape, device="cuda", generator=gen)
+    lin = H.conv5x5_fwd(0.5 * x + x2, w, None, stride) - (0.5 * y + H.conv5x5_fwd(x2, w, None, stride))
+    assert float(lin.double().norm()) <= 9e-6 * float(y.double().norm())
+    # a spot check against the fp64 oracle on a corner crop (receptive fields that see the zero padding)
+    from oracle import ops as O
+    c = 12 if stride == 1 else 16
+    ref = O.conv5x5(x[:2, :, :c, :c].cpu(), w.cpu(), None, stride)
+    k = (c - 2) // stride            # output pixels whose 5x5 window stays inside the crop
+    got = y[:2, :, :k, :k].cpu().double()
+    assert float((got - ref[:, :, :k, :k]).norm() / ref[:, :, :k, :k].norm()) <= 3e-6
+
+
+@pytest.mark.parametrize("B,Cin,Cout,Hs,stride", BIG_CONVTS)
+def test_config45_convT_adjoints(B, Cin, Cout, Hs, stride):
+    from disentangle_mlp_amd import ops as H
+    gen = torch.Generator(device="cuda").manual_seed(61)
+    x = torch.randn(B, Cin, Hs, Hs, device="cuda", generator=gen)
+    w = 0.05 * torch.randn(Cin, Cout, 5, 5, device="cuda", generator=gen)
+    y0 = H.convT5x5_fwd(x, w, None, stride)
+    assert tuple(y0.shape) == (B, Cout, stride * Hs, stride * Hs)
+    g = torch.randn(y0.shape, device="cuda", generator=gen)
+    s_fwd = _dot(y0, g)
+    s_dgrad = _dot(x, H.conv5x5_fwd(g, w, None, stride))
+    s_wgrad = _dot(w, H.conv5x5_wgrad(g, x, stride))
+    scale = float(y0.double().norm() * g.double().norm())
+    assert abs(s_fwd - s_dgrad) <= 2e-6 * scale
+    assert abs(s_fwd - s_wgrad) <= 2e-6 * scale
+    from oracle import ops as O
+    c = 8
+    ref = O.convT5x5(x[:2, :, :c, :c].cpu(), w.cpu(), None, stride)
+    k = stride * (c - 2)             # output pixels that only see the crop's inputs
+    got = y0[:2, :, :k, :k].cpu().double()
+    assert float((got - ref[:, :, :k, :k]).norm() / ref[:, :, :k, :k].norm()) <= 3e-6

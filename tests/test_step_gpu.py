@@ -328,3 +328,118 @@ def test_hip_adam_matches_torch_adam_and_shares_checkpoints(T):
     pe.grad, pf.grad = torch.ones(10).cuda(), torch.ones(10).cuda()
     oe.step(); of.step()
     assert torch.allclose(pe, pf)
+
+
+# ------------------------------------------------------------------ parity AWAY from the initial weights
+def _trained_oracle(k_iters, batch, seed=31):
+    """The oracle trained for k iterations on the host (fp32, lr 1e-3, the reference's schedule)."""
+    torch.set_num_threads(16)
+    eg, d, oeg, od = osteps.build_nets()
+    g = torch.Generator().manual_seed(seed)
+    base = torch.randn(4 * batch, 3, 8, 8, generator=g)
+    data = torch.tanh(torch.nn.functional.interpolate(base, size=64, mode="bilinear"))     # smooth "images"
+    for it in range(k_iters):
+        x = data[(it % 4) * batch:(it % 4 + 1) * batch]
+        no, e2, e3 = (torch.randn(batch, 128, generator=g) for _ in range(3))
+        osteps.betavaegan_step(eg, d, oeg, od, x, no, e2, e3, beta=25.0)
+    return eg, d, oeg, od, data, g
+
+
+def test_gradients_at_trained_weights_vs_oracle(T):
+    """`test_betavaegan_gradients_vs_live_oracle` differentiates at the initial weights only.  Here the ORACLE
+    trains k = 3 iterations on the host; its checkpoint (both models + both Adam states, the reference's dict)
+    is loaded into the HIP trainer, and ONE lr = 0 iteration on a fresh batch is compared at those trained
+    weights: losses 1e-4 and every gradient tensor of all three phases 3e-3 against the fp64 oracle holding the
+    same weights.  Phase 3 is thus checked tensor by tensor away from init (conftest.GRADNORM_TOL['EG3'] = 0.5 in
+    the golden-vector test is only a chaos bound)."""
+    batch = 8
+    eg, d, oeg, od, data, g = _trained_oracle(3, batch)
+    ck = {"epoch": 1, "encoder_decoder_model": eg.state_dict(),
+          "discriminator_model": {"module." + k: v for k, v in d.state_dict().items()},
+          "encoder_decoder_optimizer": oeg.state_dict(), "discriminator_optimizer": od.state_dict()}
+    tr = T.BetaVAEGANTrainer(beta=25.0, seed=5)            # different init: everything must come from the checkpoint
+    assert tr.load(ck) == 1
+    for o in (tr.optimizerEG, tr.optimizerD):
+        o.param_groups[0]["lr"] = 0.0
+    assert float(tr.optimizerEG.state[next(iter(tr.netEG.parameters()))]["step"]) == 6     # 2 EG steps / iteration
+    # fp64 twins of the trained oracle nets
+    eg64, d64, oeg64, od64 = osteps.build_nets(dtype=torch.float64)
+    eg64.load_state_dict(eg.state_dict())
+    d64.load_state_dict(d.state_dict())
+    for o in (oeg64, od64):
+        o.param_groups[0]["lr"] = 0.0
+    x = data[3 * batch:4 * batch]
+    no, e2, e3 = (torch.randn(batch, 128, generator=g) for _ in range(3))
+    ref_g, got_g = {}, {}
+    ref_l = osteps.betavaegan_step(eg64, d64, oeg64, od64, x.double(), no.double(), e2.double(), e3.double(), beta=25.0,
+                                   grad_hook=lambda ph, net: ref_g.__setitem__(
+                                       ph, {k: p.grad.detach().clone() for k, p in net.named_parameters()}))
+    out = tr.step(x.cuda(), no.cuda(), e2.cuda(), e3.cuda(),
+                  grad_hook=lambda ph, net: got_g.__setitem__(
+                      ph, {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}))
+    for k in ("errD_real", "errD_fake", "errG_fake", "errG_recon", "sim", "mse_dec", "kld", "mse_enc"):
+        assert close(float(out[k]), ref_l[k], 1e-4, 1e-7), (k, float(out[k]), ref_l[k])
+    worst = {}
+    for ph, key in (("D", "d"), ("EG2", "eg"), ("EG3", "eg")):
+        for k, r in ref_g[ph].items():
+            if (k in BN_SHADOWED[key] and not (k == "x_to_mu.3.bias" and ph == "EG3")) or float(r.norm()) == 0.0:
+                continue
+            e = float((got_g[ph][k].double() - r).norm() / float(r.norm()))
+            worst[ph] = max(worst.get(ph, (0.0, "")), (e, k))
+    assert all(w[0] <= 3e-3 for w in worst.values()), worst
+
+
+def test_short_trajectory_tracks_the_oracle(T):
+    """scripts/trajectory_vs_oracle.py as a test: both engines run 6 iterations on the same inputs (B = 16).
+    After Adam's first sign-like step the two are chaotic twins (the reference moves its own kld by 0.5 % with the
+    thread count), so the bounds are on trends: D(x) within 0.02 absolute, reconstruction error within 5 %, KL
+    within 15 % at every iteration; the first iteration's phase-1 numbers at 2e-5."""
+    n_it, batch = 6, 16
+    torch.set_num_threads(16)
+    g = torch.Generator().manual_seed(7)
+    base = torch.randn(4 * batch, 3, 8, 8, generator=g)
+    data = torch.tanh(torch.nn.functional.interpolate(base, size=64, mode="bilinear"))
+    tr = T.BetaVAEGANTrainer(beta=25.0)
+    eg, d, oeg, od = osteps.build_nets()
+    for it in range(n_it):
+        x = data[(it % 4) * batch:(it % 4 + 1) * batch]
+        no, e2, e3 = (torch.randn(batch, 128, generator=g) for _ in range(3))
+        out = tr.step(x.cuda(), no.cuda(), e2.cuda(), e3.cuda())
+        ref = osteps.betavaegan_step(eg, d, oeg, od, x, no, e2, e3, beta=25.0)
+        if it == 0:
+            assert close(float(out["errD_real"]), ref["errD_real"], 2e-5) and close(float(out["errD_fake"]), ref["errD_fake"], 2e-5)
+        assert abs(float(out["D_x_sum"]) / batch - ref["D_x"]) <= 0.02, (it, float(out["D_x_sum"]) / batch, ref["D_x"])
+        assert close(float(out["mse_enc"]), ref["mse_enc"], 0.05), (it, float(out["mse_enc"]), ref["mse_enc"])
+        assert close(float(out["mse_dec"]), ref["mse_dec"], 0.05), (it, float(out["mse_dec"]), ref["mse_dec"])
+        assert close(float(out["kld"]), ref["kld"], 0.15), (it, float(out["kld"]), ref["kld"])
+
+
+def test_train_epoch_on_device_loader_vs_oracle_loop(T):
+    """train_epoch (new_betavaegan.py:77-201) on the device-resident loader against the oracle driven by the same
+    batches and the same label stream: the four returned averages (two iterations, pre-chaos quantities at 1e-4)."""
+    import numpy as np
+    from disentangle_mlp_amd.data import DeviceImageDataset, DeviceLoader
+    from oracle import data as odata
+    rng = np.random.RandomState(2)
+    imgs = rng.randint(0, 256, size=(10, 64, 64, 3), dtype=np.uint8)
+    loader = DeviceLoader(DeviceImageDataset(imgs, device="cuda"), 8, shuffle=False)
+    tr = T.BetaVAEGANTrainer(beta=25.0, seed=999)
+    # the latents the trainer will draw (its own per-rank stream), replayed for the oracle
+    from disentangle_mlp_amd.trainer import _latent_generator
+    lg = _latent_generator(torch.device("cuda"), 999, 0)
+    lat = [[torch.randn(b, 128, device="cuda", generator=lg).cpu() for _ in range(3)] for b in (8, 2)]
+    enc, dec, dis, dx = tr.train_epoch(loader, label_rng=np.random.RandomState(9))
+    eg, d, oeg, od = osteps.build_nets()
+    lrng = np.random.RandomState(9)
+    mse_sum = dx_sum = 0.0
+    for i, (lo, hi) in enumerate(((0, 8), (8, 10))):
+        x = torch.stack([odata.to_tensor_normalize(imgs[j]) for j in range(lo, hi)])
+        fake = float(lrng.choice(a=[0.1, 0.9], p=[0.95, 0.05]))
+        real = float(lrng.choice(a=[0.1, 0.9], p=[0.05, 0.95]))
+        no, e2, e3 = lat[i]
+        ref = osteps.betavaegan_step(eg, d, oeg, od, x, no, e2, e3, beta=25.0, real_label=real, fake_label=fake)
+        mse_sum += ref["mse_enc"]
+        dx_sum += ref["D_x"]
+    assert enc == dec and dis == dx
+    assert close(enc, mse_sum / 10, 5e-3), (enc, mse_sum / 10)        # mse_enc follows two Adam steps: conftest LOSS_TOL
+    assert close(dx, dx_sum / 10, 2e-3), (dx, dx_sum / 10)
