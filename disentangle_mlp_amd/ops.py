@@ -100,13 +100,15 @@ def reserve_workspace(nbytes, device):
 # alone decides when weights change -- a pack is reused until `invalidate_packed_filters()`.
 USE_PACKED_FILTERS = True
 # Arithmetic of the three convolution kernels (forward, transposed = data gradient, weight gradient):
-#   "fp32"    exact fp32-input MFMA -- the product default;
-#   "bf16x6"  OPT-IN: every fp32 operand split exactly into 3 bf16 planes, 6 bf16 MFMAs per multiply, fp32
-#             accumulation: fp32-equivalent (held to the same tolerances), ~1.3x the fp32 iteration rate;
-#   "bf16x3"  OPT-IN: 2 planes (hi/lo), 3 MFMAs per multiply, ~4.5e-6 relative error per convolution, ~1.7x.
+#   "bf16x6"  the product DEFAULT: every fp32 operand split exactly into 3 bf16 planes (8 + 8 + 8 mantissa bits),
+#             the 6 plane products whose indices sum to < 3 issued on the bf16 MFMA, fp32 accumulation:
+#             fp32-equivalent (4e-7..9e-7 vs fp64 per convolution, held to the same tolerances as the exact
+#             fp32-input MFMA, whose error is 5e-7..1e-6) at 1/2.7 of its matrix-pipe cost;
+#   "fp32"    OPT-IN: exact fp32-input MFMA (v_mfma_f32_32x32x2_f32), bit-for-bit a k-ordered fmaf chain;
+#   "bf16x3"  OPT-IN: 2 planes (hi/lo), 3 MFMAs per multiply, ~4.5e-6 relative error per convolution.
 # Layers whose input channels are not a multiple of 16 (the 3-channel edges) always run the fp32 kernels.
-# Set here, or with VG_CONV_ARITH in the environment.  DESIGN.md section 8 item 1.
-CONV_ARITH = __import__("os").environ.get("VG_CONV_ARITH", "fp32")
+# Set here, or with VG_CONV_ARITH in the environment.  DESIGN.md section 2.
+CONV_ARITH = __import__("os").environ.get("VG_CONV_ARITH", "bf16x6")
 WGRAD_SPLIT = True      # within the split modes: False keeps the weight gradient on the exact-fp32 kernel
 if CONV_ARITH not in ("fp32", "bf16x3", "bf16x6"):
     raise ImportError(f"VG_CONV_ARITH={CONV_ARITH!r}: expected 'fp32', 'bf16x3' or 'bf16x6'")

@@ -12,16 +12,35 @@ from oracle import ops as O
 
 pytestmark = pytest.mark.gpu
 
-# Convolution tolerance (relative L2 against the fp64 oracle): 3e-6 for the default exact-fp32 kernels;
-# 2e-5 when the suite is run with VG_CONV_ARITH=bf16x3 exported (the opt-in 2-plane split-bf16 arithmetic);
-# VG_CONV_ARITH=bf16x6 (3 planes, the whole fp32 mantissa) is held to the fp32 tolerance.
-CONV_TOL = 2e-5 if os.environ.get("VG_CONV_ARITH", "fp32") == "bf16x3" else 3e-6      # fp32 and bf16x6: fp32-level
+# Convolution tolerance (relative L2 against the fp64 oracle): 3e-6 for the default arithmetic (bf16x6: the exact
+# 3-plane split of every fp32 operand, fp32 accumulate) AND for the exact fp32-input MFMA kernels (opt-in "fp32");
+# 2e-5 only when the suite is run with VG_CONV_ARITH=bf16x3 exported (the opt-in 2-plane split).
+CONV_TOL = 2e-5 if os.environ.get("VG_CONV_ARITH", "bf16x6") == "bf16x3" else 3e-6
 
 
 @pytest.fixture(scope="module")
 def H():
     from disentangle_mlp_amd import ops
     return ops
+
+
+@pytest.fixture(params=["default", "fp32"])
+def conv_arith(request, H):
+    """Runs a convolution test twice: in the product's default arithmetic and on the exact fp32-input MFMA
+    kernels (ops.CONV_ARITH = "fp32"), both held to CONV_TOL."""
+    prev = H.CONV_ARITH
+    if request.param != "default":
+        H.CONV_ARITH = request.param
+    yield H.CONV_ARITH
+    H.CONV_ARITH = prev
+
+
+@pytest.fixture
+def fp32_arith(H):
+    """Tests of the fp32 implicit-GEMM kernels themselves (tile variants, packed filters)."""
+    prev, H.CONV_ARITH = H.CONV_ARITH, "fp32"
+    yield
+    H.CONV_ARITH = prev
 
 
 def dev(a):
@@ -43,7 +62,7 @@ def assert_close(a, ref, tol, what=""):
 
 # ------------------------------------------------------------------ golden KATs
 @pytest.mark.parametrize("tag,stride", [("conv_s2", 2), ("conv_s1", 1), ("conv_s2b", 2)])
-def test_conv_kats(H, kats, tag, stride):
+def test_conv_kats(H, conv_arith, kats, tag, stride):
     x, w, b, gy = (dev(kats[f"{tag}/{k}"]) for k in ("x", "w", "b", "gy"))
     y = H.conv5x5_fwd(x, w, b, stride)
     assert_close(y, torch.from_numpy(kats[f"{tag}/y"]), 2e-6, tag + " fwd")
@@ -57,7 +76,7 @@ def test_conv_kats(H, kats, tag, stride):
 
 
 @pytest.mark.parametrize("tag,stride", [("convT_s2", 2), ("convT_s1", 1), ("convT_s2b", 2)])
-def test_convT_kats(H, kats, tag, stride):
+def test_convT_kats(H, conv_arith, kats, tag, stride):
     x, w, b, gy = (dev(kats[f"{tag}/{k}"]) for k in ("x", "w", "b", "gy"))
     y = H.convT5x5_fwd(x, w, b, stride)
     assert_close(y, torch.from_numpy(kats[f"{tag}/y"]), 2e-6, tag + " fwd")
@@ -127,7 +146,7 @@ def _rand(*s, seed=0):
 
 @pytest.mark.parametrize("Cin,Cout,Hs,stride", CONV_LAYERS)
 @pytest.mark.parametrize("B", [3])
-def test_conv_layers(H, Cin, Cout, Hs, stride, B):
+def test_conv_layers(H, conv_arith, Cin, Cout, Hs, stride, B):
     x, w, b = _rand(B, Cin, Hs, Hs, seed=1), 0.05 * _rand(Cout, Cin, 5, 5, seed=2), _rand(Cout, seed=3)
     y_ref = O.conv5x5(x, w, b, stride)
     y = H.conv5x5_fwd(x.cuda(), w.cuda(), b.cuda(), stride)
@@ -143,7 +162,7 @@ def test_conv_layers(H, Cin, Cout, Hs, stride, B):
 
 @pytest.mark.parametrize("Cin,Cout,Hs,stride", CONVT_LAYERS)
 @pytest.mark.parametrize("B", [3])
-def test_convT_layers(H, Cin, Cout, Hs, stride, B):
+def test_convT_layers(H, conv_arith, Cin, Cout, Hs, stride, B):
     x, w, b = _rand(B, Cin, Hs, Hs, seed=5), 0.05 * _rand(Cin, Cout, 5, 5, seed=6), _rand(Cout, seed=7)
     y_ref = O.convT5x5(x, w, b, stride)
     y = H.convT5x5_fwd(x.cuda(), w.cuda(), b.cuda(), stride)
@@ -161,7 +180,7 @@ def test_convT_layers(H, Cin, Cout, Hs, stride, B):
     (1, 1, 1, 6, 6, 2), (1, 1, 1, 5, 7, 1), (5, 7, 33, 12, 20, 2), (2, 5, 65, 10, 6, 1), (7, 2, 130, 4, 4, 2),
     (2, 9, 3, 40, 72, 2),
 ])
-def test_conv_ragged(H, B, Cin, Cout, Hs, Ws, stride):
+def test_conv_ragged(H, conv_arith, B, Cin, Cout, Hs, Ws, stride):
     """Ragged shapes: tiles partly outside the image, channel counts off the tile grid."""
     x, w, b = _rand(B, Cin, Hs, Ws, seed=9), _rand(Cout, Cin, 5, 5, seed=10), _rand(Cout, seed=11)
     y_ref = O.conv5x5(x, w, b, stride)
@@ -229,7 +248,7 @@ def test_rejects_cpu_tensors(H):
 
 
 @pytest.mark.parametrize("variant", range(8))
-def test_every_tile_variant(H, variant):
+def test_every_tile_variant(H, fp32_arith, variant):
     """The dispatcher picks tiles by grid size; force each of the 8 tile variants of the
     implicit-GEMM kernels (forward and transposed) on shapes that exercise partial tiles."""
     from disentangle_mlp_amd import _lib
@@ -255,7 +274,7 @@ def _dot(a, b):
 
 
 @pytest.mark.parametrize("Cin,Cout,Hs,stride", CONV_LAYERS)
-def test_full_size_conv_adjoints(H, Cin, Cout, Hs, stride):
+def test_full_size_conv_adjoints(H, conv_arith, Cin, Cout, Hs, stride):
     """BASELINE batch (128): <conv(x,w), g> == <x, dgrad(g,w)> == <w, wgrad(x,g)> (the three
     kernels are transposes of one bilinear map), and the forward is linear in x."""
     B = 128
@@ -276,7 +295,7 @@ def test_full_size_conv_adjoints(H, Cin, Cout, Hs, stride):
 
 
 @pytest.mark.parametrize("Cin,Cout,Hs,stride", CONVT_LAYERS)
-def test_full_size_convT_adjoints(H, Cin, Cout, Hs, stride):
+def test_full_size_convT_adjoints(H, conv_arith, Cin, Cout, Hs, stride):
     B = 128
     gen = torch.Generator(device="cuda").manual_seed(51)
     x = torch.randn(B, Cin, Hs, Hs, device="cuda", generator=gen)
@@ -321,7 +340,7 @@ def test_full_size_batchnorm_properties(H, shape):
     assert float((db.double() - gy.double().sum(dims)).abs().max()) <= 1e-4 * n ** 0.5
 
 
-def test_conv_random_shapes(H):
+def test_conv_random_shapes(H, conv_arith):
     """Seeded sweep over 30 random (B, Cin, Cout, H, W, stride) shapes: every tile-tail / channel-
     tail combination the dispatcher can hit, forward + both gradients + the transposed direction."""
     import random
@@ -353,7 +372,7 @@ def test_conv_random_shapes(H):
 @pytest.mark.parametrize("B,Cin,Cout,Hs,Ws,stride", [
     (3, 3, 32, 16, 16, 1), (2, 32, 128, 32, 32, 2), (2, 5, 130, 9, 13, 2), (2, 70, 33, 8, 8, 1),
     (1, 256, 256, 8, 8, 2)])
-def test_packed_filters_bit_identical(H, B, Cin, Cout, Hs, Ws, stride):
+def test_packed_filters_bit_identical(H, fp32_arith, B, Cin, Cout, Hs, Ws, stride):
     """vg_conv5x5_fwd_packed / vg_convT5x5_fwd_packed walk K in the same order as the plain
     entry points: results must be bit-identical on every tile variant."""
     from disentangle_mlp_amd import _lib
@@ -383,7 +402,7 @@ def test_packed_filters_bit_identical(H, B, Cin, Cout, Hs, Ws, stride):
         lib.vg_debug_set_conv_tile(1, -1)
 
 
-def test_packed_filter_cache_scope(H):
+def test_packed_filter_cache_scope(H, fp32_arith):
     """Outside a scope every launch re-packs; inside, a pack is reused until the weight's version
     changes or invalidate_packed_filters() is called (the trainer's contract)."""
     g = torch.Generator().manual_seed(6)
@@ -405,7 +424,7 @@ def test_packed_filter_cache_scope(H):
     assert torch.equal(H.conv5x5_fwd(x, w, None, 1), y0)   # leaving the scope dropped the cache
 
 
-def test_packed_filter_bad_args(H):
+def test_packed_filter_bad_args(H, fp32_arith):
     from disentangle_mlp_amd import _lib
     lib = _lib.load()
     w = torch.zeros(8, 4, 5, 5).cuda()

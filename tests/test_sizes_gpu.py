@@ -106,11 +106,14 @@ def test_config4_gan_step_128_vs_oracle():
 # ---------------------------------------------------------------- BASELINE config 5: beta-VAE-GAN at 256x256
 def test_config5_betavaegan_256_forward_and_gradients():
     """n_z = [256,32,32] (256x256 images, the two encoder heads and D's feature layer become 262144 -> 2048):
-    forward of both networks (2e-5) and one lr=0 iteration (losses 2e-4, gradients 5e-3 / 1e-2) vs the oracle at
-    B=2, beta = 75 (BASELINE config 5).  Oracle in fp32 (its three 262144x2048 weights are 2 GB each)."""
+    forward of both networks and one lr=0 iteration (losses 2e-4, gradients 5e-3 / 1e-2) vs the oracle at
+    B=4, beta = 75 (BASELINE config 5).  Oracle in fp32 (its three 262144x2048 weights are 2 GB each), so the
+    forward bound is 2e-5 for the convolutional outputs and 1e-4 behind the 262144-term fp32 dot products of the
+    Linear layers (two fp32 summation orders differ by ~sqrt(K) * 6e-8, and a BatchNorm1d over 4 samples divides
+    by a small batch deviation)."""
     from disentangle_mlp_amd import trainer as T
     from conftest import BN_SHADOWED
-    batch, zh = 2, 32
+    batch, zh = 4, 32
     torch.set_num_threads(16)
     oopt = om.OracleOpt(n_z=[256, zh, zh])
     eg, d, oeg, od = osteps.build_nets(opt=oopt)
@@ -126,9 +129,13 @@ def test_config5_betavaegan_256_forward_and_gradients():
         r_recon, r_mu, r_lv = eg(data, eps2)
         r_p, r_feat = d(data)
     assert tuple(recon.shape) == (batch, 3, 256, 256)
-    for a, b in ((recon, r_recon), (mu, r_mu), (lv, r_lv), (p, r_p), (feat, r_feat)):
+    with torch.no_grad():
+        c_got, c_ref = tr.netD.convs(data.cuda()), d.convs(data)           # the convolutional trunk alone
+        f_got, f_ref = tr.netEG.features(data.cuda()), eg.features(data)
+    for name, a, b, tol in (("D.convs", c_got, c_ref, 2e-5), ("features", f_got, f_ref, 2e-5), ("recon", recon, r_recon, 1e-4),
+                            ("mu", mu, r_mu, 1e-4), ("logvar", lv, r_lv, 1e-4), ("p", p, r_p, 1e-4), ("feat", feat, r_feat, 1e-4)):
         e = float((a.cpu().double() - b.double()).norm() / b.double().norm())
-        assert e <= 2e-5, e
+        assert e <= tol, (name, e)
     ref_g, got_g = {}, {}
     ref_l = osteps.betavaegan_step(eg, d, oeg, od, data, noise, eps2, eps3, beta=75.0,
                                    grad_hook=lambda ph, net: ref_g.__setitem__(ph, {k: q.grad.clone() for k, q in net.named_parameters()}))

@@ -349,10 +349,13 @@ def test_gradients_at_trained_weights_vs_oracle(T):
     """`test_betavaegan_gradients_vs_live_oracle` differentiates at the initial weights only.  Here the ORACLE
     trains k = 3 iterations on the host; its checkpoint (both models + both Adam states, the reference's dict)
     is loaded into the HIP trainer, and ONE lr = 0 iteration on a fresh batch is compared at those trained
-    weights: losses 1e-4 and every gradient tensor of all three phases 3e-3 against the fp64 oracle holding the
-    same weights.  Phase 3 is thus checked tensor by tensor away from init (conftest.GRADNORM_TOL['EG3'] = 0.5 in
-    the golden-vector test is only a chaos bound)."""
-    batch = 8
+    weights: losses 1e-4 and every gradient tensor of all three phases against the fp64 oracle holding the
+    same weights, to max(3e-3, 3 x the error of the reference's OWN fp32 arithmetic (the fp32 oracle, same weights,
+    same inputs) against that fp64 run) -- ReLU units whose pre-activation rounds to the other side of zero move
+    a gradient tensor by ~1e-3 each in either fp32 evaluation.  Phase 3 is thus checked tensor by tensor away from
+    init (conftest.GRADNORM_TOL['EG3'] = 0.5 in the golden-vector test is only a chaos bound)."""
+    import copy
+    batch = 16
     eg, d, oeg, od, data, g = _trained_oracle(3, batch)
     ck = {"epoch": 1, "encoder_decoder_model": eg.state_dict(),
           "discriminator_model": {"module." + k: v for k, v in d.state_dict().items()},
@@ -370,7 +373,12 @@ def test_gradients_at_trained_weights_vs_oracle(T):
         o.param_groups[0]["lr"] = 0.0
     x = data[3 * batch:4 * batch]
     no, e2, e3 = (torch.randn(batch, 128, generator=g) for _ in range(3))
-    ref_g, got_g = {}, {}
+    ref_g, got_g, ref32_g = {}, {}, {}
+    eg32, d32 = copy.deepcopy(eg), copy.deepcopy(d)            # the reference's own fp32 arithmetic at these weights
+    o32 = [torch.optim.Adam(n.parameters(), lr=0.0) for n in (eg32, d32)]
+    osteps.betavaegan_step(eg32, d32, o32[0], o32[1], x, no, e2, e3, beta=25.0,
+                           grad_hook=lambda ph, net: ref32_g.__setitem__(
+                               ph, {k: p.grad.detach().double().clone() for k, p in net.named_parameters()}))
     ref_l = osteps.betavaegan_step(eg64, d64, oeg64, od64, x.double(), no.double(), e2.double(), e3.double(), beta=25.0,
                                    grad_hook=lambda ph, net: ref_g.__setitem__(
                                        ph, {k: p.grad.detach().clone() for k, p in net.named_parameters()}))
@@ -385,8 +393,9 @@ def test_gradients_at_trained_weights_vs_oracle(T):
             if (k in BN_SHADOWED[key] and not (k == "x_to_mu.3.bias" and ph == "EG3")) or float(r.norm()) == 0.0:
                 continue
             e = float((got_g[ph][k].double() - r).norm() / float(r.norm()))
-            worst[ph] = max(worst.get(ph, (0.0, "")), (e, k))
-    assert all(w[0] <= 3e-3 for w in worst.values()), worst
+            e32 = float((ref32_g[ph][k] - r).norm() / float(r.norm()))
+            worst[ph] = max(worst.get(ph, (0.0, "", 0.0)), (e / max(3e-3, 3 * e32), k, e))
+    assert all(w[0] <= 1.0 for w in worst.values()), worst
 
 
 def test_short_trajectory_tracks_the_oracle(T):
