@@ -20,18 +20,16 @@ _P, _I, _F, _Z = c_void_p, c_int, c_float, c_size_t
 # name -> (restype, argtypes); mirrors include/vaegan_hip.h one to one
 SIGNATURES = {
     "vg_version": (_I, []),
-    "vg_debug_set_conv_tile": (_I, [_I, _I]),
-    "vg_debug_set_wgrad": (_I, [_I, _I]),
     "vg_conv5x5_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_convT5x5_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_conv5x5_packed_floats": (_Z, [_I, _I]),
     "vg_conv5x5_pack": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "vg_conv5x5_fwd_packed": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_convT5x5_fwd_packed": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "vg_debug_set_conv_bf16split_tile": (_I, [_I]),
     "vg_conv5x5_packed_bf16split_bytes": (_Z, [_I, _I, _I]),
     "vg_conv5x5_pack_bf16split": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "vg_convT5x5_fwd_bf16split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "vg_convT5x5_fwd_bf16split_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "vg_convT5x5_fwd_bf16split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "vg_conv5x5_fwd_bf16split_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "vg_conv5x5_fwd_bf16split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "vg_conv5x5_wgrad_bf16split_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
@@ -58,25 +56,67 @@ SIGNATURES = {
     "vg_image_grid_u8": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
 }
 
-_lib = None
+# the tuning build (-DVG_TUNING) adds the process-global knobs of include/vaegan_hip.h's last section
+TUNING_LIB_PATH = os.path.join(_HERE, "libvaegan_hip_tuning.so")
+TUNING_SIGNATURES = {
+    "vg_debug_set_conv_tile": (_I, [_I, _I]),
+    "vg_debug_set_wgrad": (_I, [_I, _I]),
+    "vg_debug_set_conv_bf16split_tile": (_I, [_I]),
+    "vg_debug_set_conv_ring_tile": (_I, [_I]),
+}
+
+_lib = None          # the library ops.py calls: the product one unless a test / script switched to the tuning build
+_product = None
+_tuning = None
 
 
-def load():
-    """Load the HIP library; raises (never falls back) when it is absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _open(path, signatures):
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} not found: build it with `python -m disentangle_mlp_amd.build` "
+            f"{path} not found: build it with `python -m disentangle_mlp_amd.build` "
             "(hipcc --offload-arch=gfx950). disentangle_mlp_amd has no CPU fallback.")
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in signatures.items():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing: loud by design
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
     return lib
+
+
+def load():
+    """The active HIP library (the product build unless `use_tuning(True)`); raises -- never falls back -- when
+    it is absent."""
+    global _lib, _product
+    if _lib is not None:
+        return _lib
+    if _product is None:
+        _product = _open(LIB_PATH, SIGNATURES)
+    _lib = _product
+    return _lib
+
+
+def load_tuning():
+    """libvaegan_hip_tuning.so: same kernels plus the vg_debug_* knobs.  Tests and tuning scripts only."""
+    global _tuning
+    if _tuning is None:
+        _tuning = _open(TUNING_LIB_PATH, {**SIGNATURES, **TUNING_SIGNATURES})
+    return _tuning
+
+
+class use_tuning:
+    """Context manager: route every op through the tuning build (so that a forced tile variant takes effect), and
+    back.  ``with use_tuning() as lib: lib.vg_debug_set_conv_tile(0, 3); ...``"""
+
+    def __enter__(self):
+        global _lib
+        self._prev = load()
+        _lib = load_tuning()
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._prev
+        return False
 
 
 class HipKernelError(RuntimeError):

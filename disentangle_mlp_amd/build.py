@@ -1,10 +1,15 @@
-"""Build libvaegan_hip.so (the C-ABI HIP library) in-tree for gfx950.
+"""Build libvaegan_hip.so (the C-ABI HIP library) in-tree for gfx950, and its tuning twin.
 
     python -m disentangle_mlp_amd.build [--force]
 
 hipcc cross-compiles without a GPU.  Objects are cached under csrc/build/ and
-rebuilt when a source or header is newer.  The .so is git-ignored but travels
+rebuilt when a source or header is newer.  The .so files are git-ignored but travel
 to the GPU box with the working tree.
+
+Two libraries come out of the same sources:
+  libvaegan_hip.so         the product: no global mutable state, no vg_debug_* symbols;
+  libvaegan_hip_tuning.so  compiled with -DVG_TUNING: the tile-forcing knobs (process-globals) that tests/
+                           and scripts/ use to reach every kernel variant (``_lib.load_tuning()``).
 """
 import os
 import subprocess
@@ -15,6 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 OUT = os.path.join(HERE, "libvaegan_hip.so")
+OUT_TUNING = os.path.join(HERE, "libvaegan_hip_tuning.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", f"-I{INCLUDE}", f"-I{CSRC}",
          "-Wno-unused-result"]
@@ -31,11 +37,11 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force=False, verbose=True):
+def _build_one(out, bdir_name, extra, force, verbose):
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     hdrs += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
-    bdir = os.path.join(CSRC, "build")
+    bdir = os.path.join(CSRC, "build", bdir_name) if bdir_name else os.path.join(CSRC, "build")
     os.makedirs(bdir, exist_ok=True)
     hipcc = _hipcc()
     jobs = []
@@ -46,7 +52,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + extra + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -54,12 +60,20 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(cc, jobs))
     objs = [os.path.join(bdir, s[:-4] + ".o") for s in srcs]
-    if jobs or not os.path.exists(OUT):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs
+    if jobs or not os.path.exists(out):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    return OUT
+    return out
+
+
+def build(force=False, verbose=True, tuning=True):
+    """Compiles every HIP source; returns the product library's path."""
+    out = _build_one(OUT, "", [], force, verbose)
+    if tuning:
+        _build_one(OUT_TUNING, "tuning", ["-DVG_TUNING"], force, verbose)
+    return out
 
 
 if __name__ == "__main__":

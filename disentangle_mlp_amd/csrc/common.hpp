@@ -10,6 +10,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define VG_WAVE 64
 
+// Tuning knobs (forced tile variants, split targets ...): mutable process-globals exist ONLY in the tuning build
+// (-DVG_TUNING -> libvaegan_hip_tuning.so, loaded by tests/ and scripts/ through _lib.load_tuning()); in the product
+// library they are compile-time constants and the vg_debug_* setters are absent: it holds no global mutable state
+// (include/vaegan_hip.h, "Conventions").
+#ifdef VG_TUNING
+#define VG_KNOB(type, name, value) type name = value
+#else
+#define VG_KNOB(type, name, value) constexpr type name = value
+#endif
+
 #define VG_CHECK_LAUNCH()                         \
   do {                                            \
     hipError_t e__ = hipGetLastError();           \
@@ -62,5 +72,12 @@ __host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // cross-file internal entry points (not part of the C ABI)
 int vg_internal_wgrad_reduce(const float* slabs, float* dw, int n, int splits, hipStream_t st);
+// conv_ring.hip: stride-2 split-bf16 convolution (mode 0) / transposed convolution (mode 1), 8-wave ring kernel
+size_t vg_internal_ring_workspace_bytes(int mode, int B, int Cin, int H, int W, int Cout);
+int vg_internal_ring_conv(int mode, const float* x, const void* packed, const float* bias, float* y, int B, int Cin, int H,
+                          int W, int Cout, int planes, void* workspace, size_t workspace_bytes, hipStream_t st);
+#ifdef VG_TUNING
+void vg_internal_ring_set_variant(int v);
+#endif
 int vg_internal_convT_s1_thin(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H,
                               int W, int Cout, hipStream_t st);

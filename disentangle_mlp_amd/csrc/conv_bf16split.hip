@@ -367,7 +367,7 @@ int launch_x(const float* x, const bf16x8* w, const float* bias, float* y, int B
   return 0;
 }
 
-int g_x_tile_override = -1;   // diagnostics: 0 = 128 cout x 128 px, 1 = 64 x 128, 2 = 64 x 64, 3 = 32 cout x 128 px, 4 = 32 x 256 (transposed)
+VG_KNOB(int, g_x_tile_override, -1);   // diagnostics: 0 = 128 cout x 128 px, 1 = 64 x 128, 2 = 64 x 64, 3 = 32 cout x 128 px, 4 = 32 x 256 (transposed)
 
 template <int MODE, int S, int WC, int FC, int FP, int NP>
 int dispatch_geom(const float* x, const bf16x8* w, const float* bias, float* y, int B, int Cin, int XH, int XW,
@@ -417,21 +417,34 @@ int dispatch_x(const float* x, const bf16x8* w, const float* bias, float* y, int
   return dispatch_geom<MODE, S, 2, 1, 1, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
 }
 
-// packed[class][chunk][tap][plane][k-block][CoutP] x 8 bf16 (+ one zero step at the end).
-//   transposed = 0: w is [Cout][Cin][5][5], one class of 25 taps (kh*5 + kw);
+// packed[class][chunk][step][plane][k-block][CoutP] x 8 bf16 (+ VG_PACK_SPARE zero steps at the end: the ring
+// kernel's DMA runs three steps ahead of the MFMAs).
+//   transposed = 0, S = 1: w is [Cout][Cin][5][5], one class of 25 taps (kh*5 + kw); a step is one tap, its two
+//                   k-blocks are channels 0-7 / 8-15 of the chunk;
+//   transposed = 0, S = 2 (conv_ring.hip): a step is 8 channels x 2 consecutive taps -- steps 0-11 taps (2s, 2s+1)
+//                   of channels 0-7, step 12 tap 24 of channels 0-7 | 8-15, steps 13-24 taps of channels 8-15;
 //   transposed = 1: w is [Cin][Cout][5][5], S*S parity classes, tap (a, b) of class (R, SS) is
 //                   (kh, kw) = (R + S*a, SS + S*b).
+constexpr int VG_PACK_SPARE = 3;
 __global__ __launch_bounds__(256) void pack_bf16split_kernel(const float* __restrict__ w, bf16x8* __restrict__ p,
                                                          int Cout, int Cin, int CoutP, int nsteps, int transposed,
                                                          int S, int planes) {
   const int co = blockIdx.x * 256 + threadIdx.x;
-  const int s = blockIdx.y;                 // step; s == nsteps is the spare
+  const int s = blockIdx.y;                 // step; s >= nsteps: the spares
   if (co >= CoutP) return;
   const int nchunks = Cin / 16;
   int c16 = 0, kh = 0, kw = 0;
+  int half[2] = {0, 1}, tap[2] = {-1, -1};  // per k-block: 8-channel half of the chunk, tap (-1: kh / kw below)
   const bool live = s < nsteps && co < Cout;
   if (s < nsteps) {
-    if (!transposed) {
+    if (!transposed && S == 2) {
+      c16 = s / 25;
+      const int q = s % 25;
+      for (int k = 0; k < 2; ++k) {
+        half[k] = (q < 12) ? 0 : (q == 12 ? k : 1);
+        tap[k] = (q < 12) ? 2 * q + k : (q == 12 ? 24 : 2 * (q - 13) + k);
+      }
+    } else if (!transposed) {
       c16 = s / 25;
       kh = (s % 25) / 5;
       kw = (s % 25) % 5;
@@ -455,11 +468,12 @@ __global__ __launch_bounds__(256) void pack_bf16split_kernel(const float* __rest
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
     float v[8];
+    const int t = (tap[kb] >= 0) ? tap[kb] : kh * 5 + kw;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int ci = c16 * 16 + kb * 8 + j;
+      const int ci = c16 * 16 + half[kb] * 8 + j;
       v[j] = 0.f;
-      if (live) v[j] = transposed ? w[((size_t)ci * Cout + co) * 25 + kh * 5 + kw] : w[((size_t)co * Cin + ci) * 25 + kh * 5 + kw];
+      if (live) v[j] = transposed ? w[((size_t)ci * Cout + co) * 25 + t] : w[((size_t)co * Cin + ci) * 25 + t];
     }
     for (int pl = 0; pl < planes; ++pl) {       // hi, (mid,) lo
       bf16x8 q;
@@ -494,14 +508,21 @@ int x_args_ok(const float* x, const void* packed, float* y, int B, int Cin, int 
 
 }  // namespace
 
+#ifdef VG_TUNING
 extern "C" int vg_debug_set_conv_bf16split_tile(int variant) {
   g_x_tile_override = variant;
   return 0;
 }
 
+extern "C" int vg_debug_set_conv_ring_tile(int variant) {
+  vg_internal_ring_set_variant(variant);
+  return 0;
+}
+#endif
+
 extern "C" size_t vg_conv5x5_packed_bf16split_bytes(int Cout, int Cin, int planes) {
   if (Cout <= 0 || Cin <= 0 || Cin % 16 || (planes != 2 && planes != 3)) return 0;
-  return (size_t)(Cin / 16 * 25 + 1) * 2 * planes * ((Cout + 127) & ~127) * 16;
+  return (size_t)(Cin / 16 * 25 + VG_PACK_SPARE) * 2 * planes * ((Cout + 127) & ~127) * 16;
 }
 
 extern "C" int vg_conv5x5_pack_bf16split(const float* w, void* packed, int Cout, int Cin, int transposed, int stride,
@@ -509,14 +530,19 @@ extern "C" int vg_conv5x5_pack_bf16split(const float* w, void* packed, int Cout,
   if (!w || !packed || Cout <= 0 || Cin <= 0 || Cin % 16 || ((uintptr_t)packed & 15)) return VG_ERR_BAD_ARG;
   if ((stride != 1 && stride != 2) || (planes != 2 && planes != 3)) return VG_ERR_BAD_ARG;
   const int CoutP = (Cout + 127) & ~127, nsteps = Cin / 16 * 25;
-  hipLaunchKernelGGL(pack_bf16split_kernel, dim3(cdiv(CoutP, 256), nsteps + 1), dim3(256), 0, (hipStream_t)stream, w,
-                     (bf16x8*)packed, Cout, Cin, CoutP, nsteps, transposed ? 1 : 0, transposed ? stride : 1, planes);
+  hipLaunchKernelGGL(pack_bf16split_kernel, dim3(cdiv(CoutP, 256), nsteps + VG_PACK_SPARE), dim3(256), 0,
+                     (hipStream_t)stream, w, (bf16x8*)packed, Cout, Cin, CoutP, nsteps, transposed ? 1 : 0, stride, planes);
   VG_CHECK_LAUNCH();
   return 0;
 }
 
+// Stride 2 runs on the 8-wave ring kernel (conv_ring.hip) -- except transposed convolutions with <= 64 output
+// channels, whose thin tiles (32 cout x 128 / 256 pixels) live here; stride 1 runs here.
+static bool tr_on_ring(int Cout, int stride) { return stride == 2 && Cout > 64; }
+
 extern "C" size_t vg_conv5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride) {
   if (B <= 0 || Cin <= 0 || Cin % 16 || Cout <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return 0;
+  if (stride == 2) return vg_internal_ring_workspace_bytes(0, B, Cin, H, W, Cout);
   const int k = fwd_ksplit(B, Cin, H, W, Cout, stride);
   if (k <= 1) return 0;
   return (size_t)k * B * Cout * ((H - 1) / stride + 1) * ((W - 1) / stride + 1) * sizeof(float);
@@ -527,22 +553,29 @@ extern "C" int vg_conv5x5_fwd_bf16split(const float* x, const void* packed, cons
                                      size_t workspace_bytes, void* stream) {
   if (!x_args_ok(x, packed, y, B, Cin, H, W, Cout, stride, planes)) return VG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
+  if (stride == 2)
+    return vg_internal_ring_conv(0, x, packed, bias, y, B, Cin, H, W, Cout, planes, workspace, workspace_bytes, st);
   const bf16x8* w = (const bf16x8*)packed;
   const int k = fwd_ksplit(B, Cin, H, W, Cout, stride);
   if (k > 1 && (!workspace || workspace_bytes < vg_conv5x5_fwd_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride)))
     return VG_ERR_WORKSPACE;
   const XSplit xs = {k, (float*)workspace};
-  if (planes == 2)
-    return (stride == 2) ? dispatch_x<X_FWD, 2, 2>(x, w, bias, y, B, Cin, H, W, Cout, xs, st)
-                         : dispatch_x<X_FWD, 1, 2>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
-  return (stride == 2) ? dispatch_x<X_FWD, 2, 3>(x, w, bias, y, B, Cin, H, W, Cout, xs, st)
-                       : dispatch_x<X_FWD, 1, 3>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
+  if (planes == 2) return dispatch_x<X_FWD, 1, 2>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
+  return dispatch_x<X_FWD, 1, 3>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
+}
+
+extern "C" size_t vg_convT5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride) {
+  if (B <= 0 || Cin <= 0 || Cin % 16 || Cout <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return 0;
+  return tr_on_ring(Cout, stride) ? vg_internal_ring_workspace_bytes(1, B, Cin, H, W, Cout) : 0;
 }
 
 extern "C" int vg_convT5x5_fwd_bf16split(const float* x, const void* packed, const float* bias, float* y, int B, int Cin,
-                                      int H, int W, int Cout, int stride, int planes, void* stream) {
+                                      int H, int W, int Cout, int stride, int planes, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
   if (!x_args_ok(x, packed, y, B, Cin, H, W, Cout, stride, planes)) return VG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
+  if (tr_on_ring(Cout, stride))
+    return vg_internal_ring_conv(1, x, packed, bias, y, B, Cin, H, W, Cout, planes, workspace, workspace_bytes, st);
   const bf16x8* w = (const bf16x8*)packed;
   if (planes == 2) {
     if (stride == 2) return dispatch_x<X_TR, 2, 2>(x, w, bias, y, B, Cin, H, W, Cout, XSplit{1, nullptr}, st);

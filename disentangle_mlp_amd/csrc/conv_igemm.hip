@@ -437,7 +437,11 @@ VG_PICK(8, 7, 4, 8, 8, 32, 1, 8, 2, 4, 1)
 #undef VG_PICK
 constexpr int NVAR = 8;
 
-int g_tile_override[2] = {-1, -1};  // diagnostics only (vg_debug_set_conv_tile)
+#ifdef VG_TUNING
+int g_tile_override[2] = {-1, -1};  // tuning build only (vg_debug_set_conv_tile)
+#else
+constexpr int g_tile_override[2] = {-1, -1};
+#endif
 
 template <int MODE, int S, int WIDTH, bool PK>
 int launch_var(int var, const float* x, const float* w, const float* bias, float* y, int B, int Cin, int XH,
@@ -520,11 +524,13 @@ __global__ __launch_bounds__(256) void pack_filter_kernel(const float* __restric
 
 }  // namespace
 
+#ifdef VG_TUNING
 extern "C" int vg_debug_set_conv_tile(int mode, int variant) {
   if (mode < 0 || mode > 1) return VG_ERR_BAD_ARG;
   g_tile_override[mode] = variant;
   return 0;
 }
+#endif
 
 extern "C" size_t vg_conv5x5_packed_floats(int Cout, int Cin) {
   if (Cout <= 0 || Cin <= 0) return 0;

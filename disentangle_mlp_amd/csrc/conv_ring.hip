@@ -1,0 +1,575 @@
+// Stride-2 5x5 convolution / transposed convolution forward in split-bf16 arithmetic for gfx950, with BOTH
+// MFMA operands read from LDS: vg_conv5x5_fwd_bf16split (stride 2) and vg_convT5x5_fwd_bf16split (stride 2) run
+// here.  Same arithmetic as conv_bf16split.hip (every fp32 operand split into NP bf16 planes, the plane products
+// whose indices sum to < NP on v_mfma_f32_32x32x16_bf16, fp32 accumulate; NP = 3 is the product default and
+// fp32-equivalent); nn.Conv2d / nn.ConvTranspose2d forward of /root/reference/models/model.py:392-398, 453-456,
+// 495-505 and each other's data gradients.
+//
+// Why a second kernel: in conv_bf16split.hip every wavefront fetches its filter fragments global -> VGPR
+// (8 waves x 4-6 KB per tap through the CU's vector L1) and the matrix pipe is ~55 % busy.  Here
+//   * one workgroup = 8 wavefronts (2 per SIMD) owns a CU: tile = TN cout x TM pixels, WC x WP wavefronts,
+//     FC x FP fragments of 32 x 32 each;
+//   * the pre-split, pre-packed filter ([class][chunk][step][plane][k-block][cout] x 8 bf16) is a verbatim
+//     image of what the MFMA A operand wants, so the slice of one K step (16 k) goes global -> LDS by
+//     `global_load_lds_dwordx4` DMA into a 3-slot ring, three steps ahead of its use, with counted
+//     `s_waitcnt vmcnt` and ONE raw `s_barrier` per step (never a drain);
+//   * the input patch is staged through registers (it needs the fp32 -> bf16-plane split), double-buffered:
+//     the next (half-)chunk is loaded, split and written while the current one feeds the MFMAs;
+//   * fragments for step k+1 are read (ds_read_b128, conflict-free layouts) while the MFMAs of step k run.
+// Forward (stride 2): a K step is 8 channels x 2 taps (k-block 0 / 1 = consecutive taps), so that the two
+// resident patch buffers are 8-channel halves: 25 steps per 16-channel chunk, step 12 pairs tap 24 of both
+// halves -- no padding step.  Transposed (stride 2): the 4 output-parity classes (3x3, 3x2, 2x3, 2x2 taps) as
+// in conv_igemm.hip, K step = 16 channels x 1 tap.
+#include "common.hpp"
+#include "vaegan_hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+enum { R_FWD = 0, R_TR = 1 };
+constexpr int RNT = 512;          // 8 wavefronts
+constexpr int NSLOT = 3;
+
+// 16-byte units per patch row; same bank rules as conv_bf16split.hip (fragments of 2 rows x 16 pixels need the
+// two rows 0 (mod 16) units apart, 4 rows x 8 pixels 8 (mod 16))
+constexpr int ring_cols(int mode, int TW, int PW) {
+  if (mode == R_FWD) {                                   // per column parity; a row is 2 * COLS units
+    const int need = (PW + 1) / 2;
+    if (TW == 8) { int c = need; while ((c & 3) != 2) ++c; return c; }
+    return (need + 3) & ~3;
+  }
+  if (TW == 16) return (PW + 15) & ~15;
+  if (TW == 8) { int c = PW; while ((c & 15) != 8) ++c; return c; }
+  return (PW + 3) & ~3;
+}
+
+template <int MODE_, int NB_, int TH_, int TW_, int WC_, int FC_, int FP_, int NP_>
+struct RCfg {
+  static constexpr int MODE = MODE_, NB = NB_, TH = TH_, TW = TW_, WC = WC_, WP = 8 / WC_, FC = FC_, FP = FP_, NP = NP_;
+  static constexpr int S = 2;
+  static constexpr int TN = 32 * WC * FC, TM = NB * TH * TW;
+  static constexpr int NTMAX = (MODE == R_FWD) ? 5 : 3;
+  static constexpr int PH = (MODE == R_FWD) ? S * (TH - 1) + 5 : TH + NTMAX - 1;
+  static constexpr int PW = (MODE == R_FWD) ? S * (TW - 1) + 5 : TW + NTMAX - 1;
+  static constexpr int COLS = ring_cols(MODE, TW, PW);
+  static constexpr int ROWU = (MODE == R_FWD) ? 2 * COLS : COLS;      // units per patch row
+  static constexpr int IMGU = NB * PH * ROWU;                         // units per (plane, 8-channel block) image
+  // patch buffers: FWD two 8-channel halves [half][plane][image]; TR two 16-channel chunks [buf][plane][kb][image]
+  static constexpr int BUFU = (MODE == R_FWD) ? NP * IMGU : NP * 2 * IMGU;
+  static constexpr int PATCHU = 2 * BUFU;
+  static constexpr int SLOTU = NP * 2 * TN;                            // one K step of the filter: [plane][kb][cout]
+  static constexpr int RINGU = NSLOT * SLOTU;
+  static constexpr int LDSU = RINGU + PATCHU + 1;                      // + one dummy unit for masked staging writes
+  static constexpr int DMA_TOTAL = SLOTU / 64;                         // 1 KiB DMA instructions per step
+  static constexpr int NDMA = (DMA_TOTAL + 7) / 8;                     // per wavefront (every wavefront the same count)
+  static constexpr int NUNIT = (MODE == R_FWD) ? NB * PH * PW : 2 * NB * PH * PW;   // staged units per staging event
+  static constexpr int NQ = (NUNIT + RNT - 1) / RNT;
+  static constexpr int NL = NQ * 8;                                    // plain global loads per staging event
+  static constexpr int NCLS = (MODE == R_FWD) ? 1 : 4;
+  static_assert(TM == 32 * WP * FP, "pixel tile");
+  static_assert(WC == 1 || WC == 2 || WC == 4 || WC == 8, "wavefront grid");
+  static_assert(SLOTU % 64 == 0, "a step's filter slice is whole DMA instructions");
+  static_assert(LDSU * 16 <= 160 * 1024, "LDS");
+};
+
+struct RArgs {
+  const float* x;
+  const bf16x8* w;     // packed filter
+  const float* bias;
+  float* y;
+  int B, Cin, XH, XW, Cout, CoutP, YH, YW;
+  int ntiles_n, tiles_w, tiles_hw, blocks_per_cls;
+  int cps;             // channel chunks per K split
+  size_t ysplit;       // elements per partial output slab (ksplit > 1: y points at the slabs)
+};
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// steps (of 16 k) of the transposed classes before (R, SS), per chunk of 16 channels
+__host__ __device__ constexpr int tr_taps_before(int R, int SS) {
+  int n = 0;
+  for (int r = 0; r < 2; ++r)
+    for (int s = 0; s < 2; ++s) {
+      if (r == R && s == SS) return n;
+      n += ((5 - r + 1) / 2) * ((5 - s + 1) / 2);
+    }
+  return n;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <class C, int R, int SS>
+__device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, int split) {
+  constexpr int MODE = C::MODE, S = C::S, NB = C::NB, TH = C::TH, TW = C::TW, PH = C::PH, PW = C::PW;
+  constexpr int COLS = C::COLS, ROWU = C::ROWU, IMGU = C::IMGU, NQ = C::NQ, FC = C::FC, FP = C::FP, NP = C::NP;
+  constexpr int NTMAX = C::NTMAX, BUFU = C::BUFU, SLOTU = C::SLOTU, NDMA = C::NDMA, NL = C::NL, TN = C::TN;
+  constexpr int NTH = (MODE == R_FWD) ? 5 : (5 - R + 1) / 2;     // taps along h / w in this class
+  constexpr int NTW = (MODE == R_FWD) ? 5 : (5 - SS + 1) / 2;
+  constexpr int NSTEP = NTH * NTW;                                // K steps per 16-channel chunk (FWD: 25)
+  constexpr int PSTEP = (MODE == R_FWD) ? S : 1;
+  constexpr int RING0 = 0, PATCH0 = C::RINGU, DUMMY = C::RINGU + C::PATCHU;
+
+  // Timing experiments only (scripts/abl_ring.py builds one-off libraries with -DVG_RING_ABL=bits; results are
+  // then wrong): 1 no filter DMA, 2 no barrier, 4 no patch staging, 8 no counted vmcnt wait, 16 no pixel-fragment
+  // reads, 32 no filter-fragment reads, 64 no MFMAs.  Compile-time: a run-time switch changed the schedule.
+#ifdef VG_RING_ABL
+  constexpr int abl = VG_RING_ABL;
+#else
+  constexpr int abl = 0;
+#endif
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: keeps the DMA's LDS base in SGPRs
+  const int kb = lane >> 5, l32 = lane & 31;
+  const int wc = wid % C::WC, wp = wid / C::WC;
+  // XCD-aware placement (conv_igemm.hip): the cout tiles of one pixel tile share an XCD
+  int nt, pt;
+  {
+    const int ntn = A.ntiles_n, npatch = A.blocks_per_cls / ntn, full = (npatch / 8) * 8 * ntn;
+    if (bid < full) {
+      const int xcd = bid & 7, j = bid >> 3;
+      pt = (j / ntn) * 8 + xcd;
+      nt = j % ntn;
+    } else {
+      const int t = bid - full;
+      pt = (npatch / 8) * 8 + t / ntn;
+      nt = t % ntn;
+    }
+  }
+  const int sp = pt % A.tiles_hw, bg = pt / A.tiles_hw;
+  const int th0 = (sp / A.tiles_w) * TH, tw0 = (sp % A.tiles_w) * TW;
+  const int b0 = bg * NB, n0 = nt * TN;
+  const int Cin = A.Cin, Cout = A.Cout, XH = A.XH, XW = A.XW, HW = XH * XW;
+  const int ih0 = (MODE == R_FWD) ? th0 * S - 2 : th0 - (NTMAX - 1 - 2 / S);
+  const int iw0 = (MODE == R_FWD) ? tw0 * S - 2 : tw0 - (NTMAX - 1 - 2 / S);
+  const float* xb = A.x + (size_t)b0 * Cin * HW;
+
+  // ---- staging map.  FWD: unit e = (image, row, column) of ONE 8-channel half; TR: (k-block, image, row, column).
+  // Recomputed from the thread id at every staging event (a few dozen VALU, four events per 25 steps) instead of
+  // living in registers through the MFMA loop: the loop is at the 256-VGPR budget.
+  struct Unit {
+    unsigned ofs;     // BYTE offset from a wave-uniform base: loads use the SGPR-base + 32-bit VGPR-offset form
+    int dst;          // LDS unit within a buffer's plane image, -1: not a unit of the patch
+    bool ok;          // inside the image (else zero)
+  };
+  auto unit_of = [&](int q) -> Unit {
+    int t0 = tid;
+    asm volatile("" : "+v"(t0));                       // opaque: keeps the map from being hoisted out of the loop
+    const int e = t0 + q * RNT;
+    const int col = e % PW;
+    int t = e / PW;
+    const int r = t % PH;
+    t /= PH;
+    const int nb = t % NB, kbs = (MODE == R_FWD) ? 0 : min(t / NB, 1);
+    const int ih = ih0 + r, iw = iw0 + col;
+    const bool in = e < C::NUNIT;
+    Unit u;
+    u.ok = in && ih >= 0 && ih < XH && iw >= 0 && iw < XW && (b0 + nb) < A.B;
+    const int nbc = min(nb, A.B - 1 - b0), ihc = min(max(ih, 0), XH - 1), iwc = min(max(iw, 0), XW - 1);
+    u.ofs = 4u * (unsigned)((nbc * Cin + kbs * 8) * HW + ihc * XW + iwc);
+    u.dst = in ? kbs * IMGU + (nb * PH + r) * ROWU + ((MODE == R_FWD) ? (col & 1) * COLS + (col >> 1) : col) : -1;
+    return u;
+  };
+
+  float preg[NQ][8];
+  // c0 = first channel of the 8 (FWD) / 16 (TR) channels to stage; clamped so that the address stays in the tensor
+  // (past-the-end events happen at the last chunk and are never consumed)
+  auto stage_load = [&](int c0) {
+    c0 = min(c0, Cin - ((MODE == R_FWD) ? 8 : 16));
+    unsigned ofs[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) ofs[q] = unit_of(q).ofs;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const char* xj = (const char*)(xb + (size_t)(c0 + j) * HW);      // wave-uniform
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) preg[q][j] = *(const float*)(xj + ofs[q]);
+    }
+  };
+  auto split_unit = [&](int q, int bufu) {          // fp32 -> planes of staged unit q, written to buffer `bufu`
+    const Unit u = unit_of(q);
+    bf16x8 pl[NP];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = u.ok ? preg[q][j] : 0.f;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {                // hi, (mid,) lo: each plane takes the leading 8 bits of what is left
+        const __bf16 h = (__bf16)v;
+        pl[p][j] = h;
+        v -= (float)h;
+      }
+    }
+    const int d = PATCH0 + bufu + u.dst;            // masked units go to the dummy unit (no divergent branch)
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      lds[(u.dst >= 0) ? d + p * ((MODE == R_FWD) ? IMGU : 2 * IMGU) : DUMMY] = __builtin_bit_cast(f32x4, pl[p]);
+  };
+  auto stage_store = [&](int bufu) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) split_unit(q, bufu);
+  };
+
+  // ---- filter DMA: step `st` (global step index within this class) -> ring slot `slot`
+  const int CoutP = A.CoutP;
+  const size_t wstep = (size_t)2 * NP * CoutP;      // units per step in the pack
+  const int nchunks = Cin / 16;
+  const bf16x8* wcls = A.w + (size_t)((MODE == R_FWD) ? 0 : tr_taps_before(R, SS)) * nchunks * wstep;
+  // DMA instruction i of a step covers units [64 i, 64 i + 64) of the slot image [plane][kb][TN]
+  unsigned dma_src[NDMA];     // per-lane BYTE offset within a pack step
+  int dma_dst[NDMA];          // wave-uniform unit offset within the slot
+#pragma unroll
+  for (int j = 0; j < NDMA; ++j) {
+    const int i = (wid * NDMA + j) % C::DMA_TOTAL;  // surplus instructions repeat earlier ones (same bytes, same place)
+    const int u = i * 64 + lane;                    // unit within the slot
+    const int row = u / TN, col = u % TN;           // row = plane * 2 + kb
+    dma_src[j] = 16u * (unsigned)(row * CoutP + n0 + col);
+    dma_dst[j] = i * 64;
+  }
+  const bf16x8* dma_ptr = wcls;                     // pack address of the next step to fetch (advanced by dma_next)
+  auto dma_next = [&](int slot) {
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j)
+      __builtin_amdgcn_global_load_lds((const void*)((const char*)dma_ptr + dma_src[j]),
+                                       (__attribute__((address_space(3))) void*)(lds + RING0 + slot * SLOTU + dma_dst[j]),
+                                       16, 0, 0);
+    dma_ptr += wstep;
+  };
+
+  // ---- per-lane operand bases (units)
+  int base_a[FC], base_b[FP];
+#pragma unroll
+  for (int g = 0; g < FC; ++g) base_a[g] = RING0 + kb * TN + (wc * FC + g) * 32 + l32;
+#pragma unroll
+  for (int f = 0; f < FP; ++f) {
+    const int m = (wp * FP + f) * 32 + l32;
+    const int nb = m / (TH * TW), r = m % (TH * TW);
+    base_b[f] = PATCH0 + (nb * PH + PSTEP * (r / TW)) * ROWU + r % TW + ((MODE == R_TR) ? kb * IMGU : 0);
+  }
+
+  f32x16 acc[FC][FP];
+#pragma unroll
+  for (int g = 0; g < FC; ++g)
+#pragma unroll
+    for (int f = 0; f < FP; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[g][f][r] = 0.f;
+
+  const int c_begin = split * A.cps, c_end = min(c_begin + A.cps, nchunks);
+  const int nsteps = (c_end - c_begin) * NSTEP;     // this workgroup's K steps
+  const int st0 = c_begin * NSTEP;
+
+  // patch offset (units) of K step `s` of a chunk for k-block `k`, relative to base_b: FWD buffer = 8-channel half
+  auto fwd_tap_off = [](int t) constexpr { return (t / 5) * ROWU + ((t % 5) & 1) * COLS + ((t % 5) >> 1); };
+  auto step_off = [&](int s, int k) constexpr -> int {
+    if constexpr (MODE == R_FWD) {
+      const int half = (s < 12) ? 0 : (s == 12 ? k : 1);
+      const int tap = (s < 12) ? 2 * s + k : (s == 12 ? 24 : 2 * (s - 13) + k);
+      return half * BUFU + fwd_tap_off(tap);
+    } else {
+      return (NTMAX - 1 - s / NTW) * ROWU + (NTMAX - 1 - s % NTW);
+    }
+  };
+
+  bf16x8 av[2][FC][NP], bv[2][FP][NP];
+  // Fragment read j of a step (j < NRD): the FC * NP filter fragments, then the FP * NP pixel fragments.
+  constexpr int NRD = (FC + FP) * NP;
+  auto read_one = [&](int buf, int j, int so, int bo) {
+    if (j < FC * NP) {
+      const int g = j / NP, p = j % NP;
+      av[buf][g][p] = __builtin_bit_cast(bf16x8, lds[base_a[g] + so + p * 2 * TN]);
+    } else {
+      const int f = (j - FC * NP) / NP, p = (j - FC * NP) % NP;
+      bv[buf][f][p] = __builtin_bit_cast(bf16x8, lds[base_b[f] + bo + p * ((MODE == R_FWD) ? IMGU : 2 * IMGU)]);
+    }
+  };
+  // patch offset of chunk-step s for this lane's k-block (+ TR: the chunk's patch buffer)
+  auto patch_off = [&](int s, int pbuf) -> int {
+    if constexpr (MODE == R_FWD) return kb ? step_off(s, 1) : step_off(s, 0);
+    else return pbuf + step_off(s, 0);
+  };
+  // MFMA i of a step (i < NMF): plane products with index sum < NP, smallest terms first, all fragments per product
+  constexpr int NPROD = NP * (NP + 1) / 2, NMF = NPROD * FC * FP;
+  auto mfma_one = [&](int buf, int i) {
+    const int pr = i / (FC * FP), g = (i / FP) % FC, f = i % FP;
+    int pa = 0, pb = 0, n = 0;                       // pr-th pair in the order (sum = NP-1 .. 0; pa = sum .. 0)
+#pragma unroll
+    for (int sum = NP - 1; sum >= 0; --sum)
+#pragma unroll
+      for (int a = sum; a >= 0; --a) {
+        if (n == pr) { pa = a; pb = sum - a; }
+        ++n;
+      }
+    acc[g][f] = mfma_bf16(av[buf][g][pa], bv[buf][f][pb], acc[g][f]);
+  };
+  // a step's MFMAs with the next step's fragment reads spread between them (one read per RS MFMAs), pinned
+  constexpr int RS = (NMF / NRD) > 0 ? (NMF / NRD) : 1;
+  // ---- prologue: first patch buffer, ring slots 0..2, fragments of step 0
+  dma_ptr += (size_t)st0 * wstep;
+  dma_next(0);
+  dma_next(1);
+  dma_next(2);
+  stage_load(c_begin * 16);
+  stage_store(0);
+  wait_vmcnt<0>();
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NRD; ++j) read_one(0, j, 0, patch_off(0, 0));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  int slot = 0;        // ring slot of the current step
+  for (int ch = c_begin; ch < c_end; ++ch) {
+    const int pcur = (MODE == R_TR) ? ((ch - c_begin) & 1) * BUFU : 0;
+    const int pnxt = (MODE == R_TR) ? BUFU - pcur : 0;
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      const int cur = s & 1, nxt = cur ^ 1;
+      // staging events of this body.  FWD: half B of this chunk is loaded at body 0 and written at body 4 (needed
+      // by the reads of step 12, issued in body 11); half A of the NEXT chunk is loaded at body 13 (its buffer is
+      // free once step 12 has been read) and written at body 17.  TR: the next chunk at body 0 / body LW.
+      constexpr int LW = (NSTEP >= 6) ? 3 : 2;
+      const bool ld = (MODE == R_FWD) ? (s == 0 || s == 13) : (s == 0);
+      const bool wr = (MODE == R_FWD) ? (s == 4 || s == 17) : (s == LW);
+      const int wbuf = (MODE == R_FWD) ? (s == 4 ? BUFU : 0) : pnxt;
+      if (!(abl & 2)) __builtin_amdgcn_s_barrier();       // B_k: slot (k+1)%3 and the patch writes of body k-1 are visible
+      __builtin_amdgcn_sched_barrier(0);
+      const int nslot = (slot == NSLOT - 1) ? 0 : slot + 1;
+      const int so = nslot * SLOTU;
+      // the next step's patch offset (the last body reads step 0 of the next chunk)
+      const int bo = (s + 1 < NSTEP) ? patch_off(s + 1, pcur) : patch_off(0, pnxt);
+#pragma unroll
+      for (int i = 0; i < NMF; ++i) {
+        if (!(abl & 64)) mfma_one(cur, i);
+        if (i == 0) {
+          if (!(abl & 1)) dma_next(slot);                  // step k+3 into the slot read during body k-1
+          if (ld && !(abl & 4)) {
+            if constexpr (MODE == R_FWD) stage_load(ch * 16 + (s == 0 ? 8 : 16));
+            else stage_load((ch + 1) * 16);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (i % RS == RS - 1 && i / RS < NRD) {
+          if (!(abl & ((i / RS < FC * NP) ? 32 : 16))) read_one(nxt, i / RS, so, bo);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // a written unit's split (VALU) + ds_writes go between the later MFMAs
+        if (wr && !(abl & 4) && i >= NMF / 2 && (i - NMF / 2) < NQ) {
+          split_unit(i - NMF / 2, wbuf);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int j = NMF / RS; j < NRD; ++j) read_one(nxt, j, so, bo);     // reads the MFMA count left over
+      if (wr && !(abl & 4)) {
+#pragma unroll
+        for (int q = NMF - NMF / 2; q < NQ; ++q) split_unit(q, wbuf);
+      }
+      // DMA(k+2) has landed (DMA(k+3), and a staging event's loads for two bodies, stay in flight);
+      // this wavefront's reads of step k+1 and its patch writes are done
+      __builtin_amdgcn_sched_barrier(0);
+      const bool ldw = (MODE == R_FWD) ? (s == 0 || s == 1 || s == 13 || s == 14) : (s == 0 || s == 1);
+      if (abl & (8 | 4 | 1)) {                                      // ablations change what is in flight: drain or skip
+        if (!(abl & 8)) wait_vmcnt<0>();
+      } else if (ldw) wait_vmcnt<NDMA + NL>(); else wait_vmcnt<NDMA>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      slot = nslot;
+    }
+    if constexpr (NSTEP & 1) {     // odd step count: the fragments just read sit in set 1, the next chunk starts on set 0
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int g = 0; g < FC; ++g) av[0][g][p] = av[1][g][p];
+#pragma unroll
+        for (int f = 0; f < FP; ++f) bv[0][f][p] = bv[1][f][p];
+      }
+    }
+  }
+  wait_vmcnt<0>();     // nothing of the ring is in flight when the workgroup ends
+
+  // ---- epilogue: + bias, NCHW store (as conv_igemm.hip)
+  const int YH = A.YH, YW = A.YW;
+#pragma unroll
+  for (int f = 0; f < FP; ++f) {
+    const int m = (wp * FP + f) * 32 + l32;
+    const int nb = m / (TH * TW), r = m % (TH * TW);
+    const int th = th0 + r / TW, tw = tw0 + r % TW, b = b0 + nb;
+    const int oh = (MODE == R_FWD) ? th : S * th + R;
+    const int ow = (MODE == R_FWD) ? tw : S * tw + SS;
+    const bool pok = b < A.B && oh < YH && ow < YW;
+    float* yb = A.y + (size_t)split * A.ysplit + ((size_t)b * Cout * YH + oh) * YW + ow;
+#pragma unroll
+    for (int g = 0; g < FC; ++g) {
+      float bvv[16];
+#pragma unroll
+      for (int r16 = 0; r16 < 16; ++r16) {
+        const int co = min(n0 + (wc * FC + g) * 32 + acc_row(r16, lane), Cout - 1);
+        bvv[r16] = (A.bias && split == 0) ? A.bias[co] : 0.f;     // partial slabs: the bias goes in once
+      }
+#pragma unroll
+      for (int r16 = 0; r16 < 16; ++r16) {
+        const int co = n0 + (wc * FC + g) * 32 + acc_row(r16, lane);
+        if (pok && co < Cout) yb[(size_t)co * YH * YW] = acc[g][f][r16] + bvv[r16];
+      }
+    }
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(RNT, 2) void conv5x5_ring_kernel(RArgs A) {
+  __shared__ f32x4 lds[C::LDSU];     // ONE array: [filter ring 3 slots][patch buffers][dummy]
+  int bid = blockIdx.x;
+  if constexpr (C::NCLS == 1) {
+    const int split = bid / A.blocks_per_cls;
+    ring_body<C, 0, 0>(A, lds, bid - split * A.blocks_per_cls, split);
+  } else {
+    // [class][split][tile]; class 0 (3x3 taps) first: the longest blocks start earliest
+    const int per = A.blocks_per_cls;
+    const int nsplit = gridDim.x / (4 * per);
+    const int cls = bid / (per * nsplit);
+    bid -= cls * per * nsplit;
+    const int split = bid / per;
+    bid -= split * per;
+    switch (cls) {
+      case 0: ring_body<C, 0, 0>(A, lds, bid, split); break;
+      case 1: ring_body<C, 0, 1>(A, lds, bid, split); break;
+      case 2: ring_body<C, 1, 0>(A, lds, bid, split); break;
+      default: ring_body<C, 1, 1>(A, lds, bid, split); break;
+    }
+  }
+}
+
+template <class C>
+int launch_ring(const float* x, const bf16x8* w, const float* bias, float* y, int B, int Cin, int XH, int XW, int Cout,
+                int ksplit, float* slabs, hipStream_t st) {
+  RArgs A;
+  A.x = x; A.w = w; A.bias = bias; A.y = y;
+  A.B = B; A.Cin = Cin; A.XH = XH; A.XW = XW; A.Cout = Cout; A.CoutP = (Cout + 127) & ~127;
+  int tsh, tsw;
+  if (C::MODE == R_FWD) {
+    A.YH = (XH - 1) / 2 + 1; A.YW = (XW - 1) / 2 + 1;
+    tsh = A.YH; tsw = A.YW;
+  } else {
+    A.YH = XH * 2; A.YW = XW * 2;
+    tsh = XH; tsw = XW;
+  }
+  A.tiles_w = cdiv(tsw, C::TW);
+  A.tiles_hw = cdiv(tsh, C::TH) * A.tiles_w;
+  A.ntiles_n = cdiv(Cout, C::TN);
+  const long per_cls = (long)A.ntiles_n * A.tiles_hw * cdiv(B, C::NB);
+  const long grid = per_cls * C::NCLS * ksplit;
+  if (grid <= 0 || grid > 0x7fffffffL) return VG_ERR_BAD_ARG;
+  A.blocks_per_cls = (int)per_cls;
+  A.cps = cdiv(Cin / 16, ksplit);
+  A.ysplit = (size_t)B * Cout * A.YH * A.YW;
+  if (ksplit > 1) A.y = slabs;
+  hipLaunchKernelGGL(conv5x5_ring_kernel<C>, dim3((unsigned)grid), dim3(RNT), 0, st, A);
+  VG_CHECK_LAUNCH();
+  if (ksplit > 1) {
+    if (A.ysplit > 0x7fffffffUL) return VG_ERR_BAD_ARG;
+    return vg_internal_wgrad_reduce(slabs, y, (int)A.ysplit, ksplit, st);   // fixed-order sum of the slabs
+  }
+  return 0;
+}
+
+// pixel-tile geometry by the width of the tiled image (forward: output, transposed: input)
+template <int MODE, int WC, int FC, int FP, int NP>
+int ring_geom(const float* x, const bf16x8* w, const float* bias, float* y, int B, int Cin, int XH, int XW, int Cout,
+              int ksplit, float* slabs, hipStream_t st) {
+  const int tsw = (MODE == R_FWD) ? (XW - 1) / 2 + 1 : XW;
+  constexpr int TM = 32 * (8 / WC) * FP;
+  static_assert(TM == 128 || TM == 256, "pixel tile");
+  if constexpr (TM == 128) {
+    if (tsw > 8) return launch_ring<RCfg<MODE, 1, 8, 16, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, st);
+    // transposed, 8-wide images, 256 cout: ring + the two 2 x 10 x 10 patches (24 units per row) exceed the LDS;
+    // the plan sends those layers to the 128-cout tiles
+    if constexpr (MODE == R_TR && WC * FC * 32 == 256) return VG_ERR_BAD_ARG;
+    else return launch_ring<RCfg<MODE, 2, 8, 8, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, st);
+  } else {   // 256 pixels: whole 16 x 16 tiles only (the plan never picks it for narrower images)
+    return launch_ring<RCfg<MODE, 1, 16, 16, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, st);
+  }
+}
+
+VG_KNOB(int, g_ring_variant, -1);   // tuning build only: forced tile variant
+
+}  // namespace
+
+// Tile variants.  0: 256 cout x 128 px (4 x 2 wavefronts of 64 x 64); 1: 128 cout x 128 px (2 x 4 wavefronts of
+// 64 cout x 32 px); 2: 128 cout x 128 px (4 x 2 wavefronts of 32 cout x 64 px); 3 (transposed only, small patch):
+// 128 cout x 256 px (2 x 4 wavefronts of 64 x 64).
+template <int MODE, int NP>
+static int ring_dispatch(int variant, const float* x, const bf16x8* w, const float* bias, float* y, int B, int Cin, int XH,
+                         int XW, int Cout, int ksplit, float* slabs, hipStream_t st) {
+  switch (variant) {
+    case 0: return ring_geom<MODE, 4, 2, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, st);
+    case 1: return ring_geom<MODE, 2, 2, 1, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, st);
+    case 2: return ring_geom<MODE, 4, 1, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, st);
+    default:
+      if constexpr (MODE == R_TR) return ring_geom<MODE, 2, 2, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, st);
+      return VG_ERR_BAD_ARG;
+  }
+}
+
+// ---- decisions shared with conv_bf16split.hip ------------------------------------------------------------------
+// K split (channel chunks over workgroups, partial outputs summed in a fixed order) for layers whose tile grid
+// leaves CUs idle: the smallest power of two that gives >= 192 workgroups, every split owning >= 2 chunks.
+static int ring_ksplit(long wgs, int nchunks) {
+  int k = 1;
+  while (wgs * k < 192 && k < 8 && nchunks / (2 * k) >= 2 && (2 * k - 1) * cdiv(nchunks, 2 * k) < nchunks) k *= 2;
+  return k;
+}
+
+struct RingPlan {
+  int variant, ksplit;
+};
+
+static RingPlan ring_plan(int mode, int B, int Cin, int XH, int XW, int Cout) {
+  const int tsw = (mode == R_FWD) ? (XW - 1) / 2 + 1 : XW, tsh = (mode == R_FWD) ? (XH - 1) / 2 + 1 : XH;
+  const int ncls = (mode == R_TR) ? 4 : 1;
+  // pixel tiles of 128 (geometry 8 x 16 per image, or 2 images x 8 x 8)
+  const long pt128 = (tsw > 8) ? (long)B * cdiv(tsh, 8) * cdiv(tsw, 16) : (long)cdiv(B, 2) * cdiv(tsh, 8) * cdiv(tsw, 8);
+  RingPlan p;
+  // measured at B = 128 (scripts/time_ring.py): 256-cout tiles for wide layers; for <= 128 output channels the
+  // 4 x 2 wavefront arrangement (32 cout x 64 px per wavefront), and for the transposed form -- small patch -- the
+  // 256-pixel tile when the image has whole 16 x 16 tiles
+  if (Cout > 128) p.variant = 0;
+  else p.variant = (mode == R_TR && tsw >= 16 && tsh >= 16) ? 3 : 2;
+  if (g_ring_variant >= 0) p.variant = g_ring_variant;
+  if (p.variant == 3 && (mode == R_FWD || tsw <= 8)) p.variant = 1;
+  if (p.variant == 0 && mode == R_TR && tsw <= 8) p.variant = 2;
+  const int tn = (p.variant == 0) ? 256 : 128;
+  const long wgs = ((p.variant == 3) ? (pt128 + 1) / 2 : pt128) * cdiv(Cout, tn) * ncls;
+  p.ksplit = ring_ksplit(wgs, Cin / 16);
+  return p;
+}
+
+size_t vg_internal_ring_workspace_bytes(int mode, int B, int Cin, int H, int W, int Cout) {
+  const RingPlan p = ring_plan(mode, B, Cin, H, W, Cout);
+  if (p.ksplit <= 1) return 0;
+  const size_t yh = (mode == R_FWD) ? (H - 1) / 2 + 1 : 2 * H, yw = (mode == R_FWD) ? (W - 1) / 2 + 1 : 2 * W;
+  return (size_t)p.ksplit * B * Cout * yh * yw * sizeof(float);
+}
+
+int vg_internal_ring_conv(int mode, const float* x, const void* packed, const float* bias, float* y, int B, int Cin, int H,
+                          int W, int Cout, int planes, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  const RingPlan p = ring_plan(mode, B, Cin, H, W, Cout);
+  if (p.ksplit > 1 && (!workspace || workspace_bytes < vg_internal_ring_workspace_bytes(mode, B, Cin, H, W, Cout)))
+    return VG_ERR_WORKSPACE;
+  const bf16x8* w = (const bf16x8*)packed;
+  float* slabs = (float*)workspace;
+  if (mode == R_FWD) {
+    if (planes == 3) return ring_dispatch<R_FWD, 3>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, st);
+    return ring_dispatch<R_FWD, 2>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, st);
+  }
+  if (planes == 3) return ring_dispatch<R_TR, 3>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, st);
+  return ring_dispatch<R_TR, 2>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, st);
+}
+
+#ifdef VG_TUNING
+void vg_internal_ring_set_variant(int v) { g_ring_variant = v; }
+#endif

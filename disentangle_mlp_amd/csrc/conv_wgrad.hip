@@ -265,11 +265,11 @@ struct Plan {
   int tw, tm, cit, mtiles, ntiles, splits, tiles_w, tiles_hw, chunks, cps, OH, OW;
 };
 
-int g_wgrad_ks = 2;                 // 8-wave K-split kernel for the 128-row tile (1 = 4-wave form, diagnostics)
-int g_wgrad_cit = 5;                // 10 = 250-column tile for the 128-row tile (measured slower: diagnostics)
-int g_wgrad_vec4 = 1;               // diagnostics: 0 = scalar gy loads everywhere
-int g_wgrad_tm_override = -1;       // diagnostics only (vg_debug_set_conv_tile mode 2)
-int g_wgrad_blocks_target = -1;     // diagnostics only
+VG_KNOB(int, g_wgrad_ks, 2);                 // 8-wave K-split kernel for the 128-row tile (1 = 4-wave form, diagnostics)
+VG_KNOB(int, g_wgrad_cit, 5);                // 10 = 250-column tile for the 128-row tile (measured slower: diagnostics)
+VG_KNOB(int, g_wgrad_vec4, 1);               // diagnostics: 0 = scalar gy loads everywhere
+VG_KNOB(int, g_wgrad_tm_override, -1);       // diagnostics only (vg_debug_set_conv_tile mode 2)
+VG_KNOB(int, g_wgrad_blocks_target, -1);     // diagnostics only
 
 Plan make_plan(int B, int Cin, int H, int W, int Cout, int S) {
   Plan p;
@@ -336,6 +336,7 @@ int vg_internal_wgrad_reduce(const float* slabs, float* dw, int n, int splits, h
   return 0;
 }
 
+#ifdef VG_TUNING
 extern "C" int vg_debug_set_wgrad(int what, int value) {
   if (what == 0) g_wgrad_tm_override = value;
   else if (what == 1) g_wgrad_blocks_target = value;
@@ -345,6 +346,7 @@ extern "C" int vg_debug_set_wgrad(int what, int value) {
   else return VG_ERR_BAD_ARG;
   return 0;
 }
+#endif
 
 extern "C" size_t vg_conv5x5_wgrad_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride) {
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return 0;

@@ -213,7 +213,7 @@ def conv5x5_fwd(x, w, bias, stride):
     OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
     y = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
     if _planes() and Cin % 16 == 0:
-        pk = _packed_filter(lib, w, Cout, Cin, 2, 1)
+        pk = _packed_filter(lib, w, Cout, Cin, 2, stride)      # the stride-2 kernel has its own step order
         need = lib.vg_conv5x5_fwd_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride)    # split-K slabs, deep-K layers only
         ws = workspace(need, x.device) if need else None
         with _timed(("conv_fwd", B, Cin, H, W, Cout, stride)):
@@ -248,9 +248,12 @@ def convT5x5_fwd(x, w, bias, stride):
     thin = stride == 1 and Cout <= 4
     if _planes() and Cin % 16 == 0 and not thin:
         pk = _packed_filter(lib, w, Cout, Cin, 3, stride)
+        need = lib.vg_convT5x5_fwd_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride)   # split-K slabs, small grids only
+        ws = workspace(need, x.device) if need else None
         with _timed(("convT_fwd", B, Cin, H, W, Cout, stride)):
             check(lib.vg_convT5x5_fwd_bf16split(x.data_ptr(), pk.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W,
-                                             Cout, stride, _planes(), _stream()), "vg_convT5x5_fwd_bf16split")
+                                             Cout, stride, _planes(), _ptr(ws), ws.numel() if need else 0, _stream()),
+                  "vg_convT5x5_fwd_bf16split")
         return y
     if USE_PACKED_FILTERS and not thin:
         pk = _packed_filter(lib, w, Cout, Cin, 1, stride)

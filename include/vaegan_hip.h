@@ -18,7 +18,9 @@
  *     argument, VG_ERR_WORKSPACE (-2) for a too-small workspace, otherwise the
  *     hipError_t of the failed launch.  No exceptions cross the ABI.
  *   - launches are asynchronous, hold no global mutable state and are
- *     HIP-graph capturable.
+ *     HIP-graph capturable.  (The tile-forcing knobs tests and tuning scripts use are process-globals,
+ *     so they exist only in a second build of the same sources, libvaegan_hip_tuning.so, compiled with
+ *     -DVG_TUNING: the section at the end of this header.)
  */
 #ifndef VAEGAN_HIP_H
 #define VAEGAN_HIP_H
@@ -39,15 +41,6 @@ extern "C" {
 #define VG_ACT_LRELU 2 /* nn.LeakyReLU(.2) model.py:391,404     */
 
 int vg_version(void);
-
-/* Diagnostics / tuning only: force tile variant `variant` (>= 0; -1 restores the
- * heuristic) for mode 0 (vg_conv5x5_fwd) or 1 (vg_convT5x5_fwd).  Process-global;
- * never used by the product path. */
-int vg_debug_set_conv_tile(int mode, int variant);
-/* Diagnostics / tuning only: what=0 caps the wgrad cout tile (32/64/128, -1 = heuristic);
- * what=1 sets the split-K workgroup target (-1 = heuristic); what=2 the K groups of the 128-row
- * tile (1 or 2); what=3 the input channels per column tile (5 or 10); what=4: 0 = scalar gy loads. */
-int vg_debug_set_wgrad(int what, int value);
 
 /* ---- 5x5 convolutions, padding 2, stride 1 or 2 ----------------------------
  * y[B,Cout,OH,OW] = conv2d(x[B,Cin,H,W], w[Cout,Cin,5,5]) + bias;  OH=(H-1)/s+1.
@@ -82,27 +75,32 @@ int vg_conv5x5_fwd_packed(const float* x, const float* packed, const float* bias
 int vg_convT5x5_fwd_packed(const float* x, const float* packed, const float* bias, float* y,
                            int B, int Cin, int H, int W, int Cout, int stride, void* stream);
 
-/* OPT-IN arithmetic modes of vg_conv5x5_fwd / vg_convT5x5_fwd (not used by default; DESIGN.md
- * section 8): every fp32 operand is split into `planes` bf16 values and the products whose plane indices
- * sum to < planes are evaluated on the bf16 MFMA with fp32 accumulation:
- *   planes = 2  hi/lo, 3 MFMAs per product ("bf16x3"): ~4.5e-6 relative error against fp64
- *               (the exact-fp32 kernels: 5e-7..1e-6);
+/* Split-bf16 arithmetic of vg_conv5x5_fwd / vg_convT5x5_fwd: every fp32 operand is split
+ * into `planes` bf16 values and the products whose plane indices sum to < planes are evaluated on the bf16
+ * MFMA (v_mfma_f32_32x32x16_bf16) with fp32 accumulation:
  *   planes = 3  hi/mid/lo = the whole 24-bit mantissa, 6 MFMAs per product ("bf16x6"): every dropped
- *               term is below 2^-24 -- fp32-equivalent.
+ *               term is below 2^-24 -- fp32-equivalent (4e-7..9e-7 against fp64; the exact fp32-input
+ *               MFMA kernels above: 5e-7..1e-6).  THE PRODUCT DEFAULT of the Python layer.
+ *   planes = 2  hi/lo, 3 MFMAs per product ("bf16x3"): ~4.5e-6 relative error; opt-in.
  * Requires Cin % 16 == 0.  `packed` holds vg_conv5x5_packed_bf16split_bytes(Cout, Cin, planes) bytes
  * (16-byte aligned), written by vg_conv5x5_pack_bf16split once per weight version:
- *   transposed = 0: from w[Cout,Cin,5,5] for vg_conv5x5_fwd_bf16split (stride ignored);
- *   transposed = 1: from w[Cin,Cout,5,5] for vg_convT5x5_fwd_bf16split with the SAME stride. */
-int vg_debug_set_conv_bf16split_tile(int variant);   /* tuning only: 0 = 128x128, 1 = 64x128, 2 = 64x64, 3 = 32x128, 4 = 32x256 (transposed), 5 = 128x128 with the 4 wavefronts along cout, -1 = heuristic */
+ *   transposed = 0: from w[Cout,Cin,5,5] for vg_conv5x5_fwd_bf16split with the SAME stride (the stride-2
+ *                   kernel pairs taps differently from the stride-1 one);
+ *   transposed = 1: from w[Cin,Cout,5,5] for vg_convT5x5_fwd_bf16split with the SAME stride.
+ * Stride 2 runs on the 8-wavefront kernel of conv_ring.hip (both MFMA operands from LDS, the filter through a
+ * global_load_lds DMA ring); layers whose tile grid would leave CUs idle split their input channels over
+ * workgroups and sum the partial outputs in a fixed order: query the workspace (0 for most shapes). */
 size_t vg_conv5x5_packed_bf16split_bytes(int Cout, int Cin, int planes);
 int vg_conv5x5_pack_bf16split(const float* w, void* packed, int Cout, int Cin, int transposed, int stride,
                            int planes, void* stream);
-size_t vg_conv5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride);   /* 0 for most shapes */
+size_t vg_conv5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride);
 int vg_conv5x5_fwd_bf16split(const float* x, const void* packed, const float* bias, float* y,
                           int B, int Cin, int H, int W, int Cout, int stride, int planes,
                           void* workspace, size_t workspace_bytes, void* stream);
+size_t vg_convT5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride);
 int vg_convT5x5_fwd_bf16split(const float* x, const void* packed, const float* bias, float* y,
-                           int B, int Cin, int H, int W, int Cout, int stride, int planes, void* stream);
+                           int B, int Cin, int H, int W, int Cout, int stride, int planes,
+                           void* workspace, size_t workspace_bytes, void* stream);
 /* vg_conv5x5_wgrad in the same opt-in arithmetic.  The reduction runs over images in groups of 16
  * (operands re-laid batch-innermost inside the call; B is zero-padded to a multiple of 16); needs
  * OH % 4 == 0 (planes = 2) or OH % 2 == 0 (planes = 3) and OW % 8 == 0 -- the workspace query returns 0 for shapes it does not take
@@ -226,6 +224,24 @@ int vg_minmax(const float* x, size_t n, float* out2, void* workspace, size_t wor
 int vg_image_grid_shape(int B, int H, int W, int nrow, int padding, int* grid_h, int* grid_w);
 int vg_image_grid_u8(const float* x, const float* minmax, uint8_t* grid, int B, int C, int H, int W,
                      int nrow, int padding, float pad_value, void* stream);
+
+#ifdef VG_TUNING
+/* ---- tuning build only (libvaegan_hip_tuning.so): process-global knobs, never in the product library ---- */
+/* Diagnostics / tuning only: force tile variant `variant` (>= 0; -1 restores the
+ * heuristic) for mode 0 (vg_conv5x5_fwd) or 1 (vg_convT5x5_fwd).  Process-global;
+ * never used by the product path. */
+int vg_debug_set_conv_tile(int mode, int variant);
+/* Diagnostics / tuning only: what=0 caps the wgrad cout tile (32/64/128, -1 = heuristic);
+ * what=1 sets the split-K workgroup target (-1 = heuristic); what=2 the K groups of the 128-row
+ * tile (1 or 2); what=3 the input channels per column tile (5 or 10); what=4: 0 = scalar gy loads. */
+int vg_debug_set_wgrad(int what, int value);
+/* split-bf16 kernels of conv_bf16split.hip: 0 = 128x128, 1 = 64x128, 2 = 64x64, 3 = 32x128, 4 = 32x256 (transposed),
+ * 5 = 128x128 with the 4 wavefronts along cout, -1 = heuristic */
+int vg_debug_set_conv_bf16split_tile(int variant);
+/* stride-2 ring kernel of conv_ring.hip: 0 = 256 cout x 128 px, 1 / 2 = 128 x 128 (2x4 / 4x2 wavefronts),
+ * 3 = 128 x 256 (transposed), -1 = heuristic */
+int vg_debug_set_conv_ring_tile(int variant);
+#endif
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@ from disentangle_mlp_amd import _lib
 from disentangle_mlp_amd.trainer import BetaVAEGANTrainer
 
 what, va, vb = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-lib = _lib.load()
+lib = _lib.use_tuning().__enter__()      # the vg_debug_* knobs live in the tuning build only
 tr = BetaVAEGANTrainer(beta=25.0)
 x = (torch.rand(128, 3, 64, 64) * 2 - 1).cuda()
 for _ in range(5):

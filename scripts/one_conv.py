@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from disentangle_mlp_amd import ops, _lib
-lib = _lib.load()
+lib = _lib.use_tuning().__enter__()      # the vg_debug_* knobs live in the tuning build only
 mode, var, cin, cout, h = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 B = 128
 x = torch.randn(B, cin, h, h, device="cuda")

@@ -5,7 +5,7 @@ import torch
 from disentangle_mlp_amd import ops
 from oracle import ops as O
 from disentangle_mlp_amd import _lib
-lib = _lib.load()
+lib = _lib.use_tuning().__enter__()      # the vg_debug_* knobs live in the tuning build only
 
 B = 128
 L = [("dis.c3", 32, 128, 64, 2), ("dis.c6", 128, 256, 32, 2), ("dis.c9", 256, 256, 16, 2), ("enc.f3", 64, 128, 32, 2),

@@ -2,7 +2,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from disentangle_mlp_amd import ops, _lib
-lib = _lib.load()
+lib = _lib.use_tuning().__enter__()      # the vg_debug_* knobs live in the tuning build only
 B = 128
 L = [("dis.c3", 32, 128, 64, 2), ("dis.c6", 128, 256, 32, 2), ("dis.c9", 256, 256, 16, 2), ("enc.f3", 64, 128, 32, 2),
      ("enc.f6", 128, 256, 16, 2), ("dis.c0", 3, 32, 64, 1), ("enc.f0", 3, 64, 64, 2)]

@@ -15,21 +15,40 @@ def lib_path():
     return build.build(verbose=False)
 
 
-def declared_symbols():
+def declared_symbols(tuning=False):
+    """Entry points the header declares: the product ABI, or the `#ifdef VG_TUNING` section (the process-global
+    knobs that exist only in libvaegan_hip_tuning.so)."""
     text = open(os.path.join(ROOT, "include", "vaegan_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    m = re.search(r"#ifdef VG_TUNING(.*?)#endif", text, flags=re.S)
+    assert m, "the header keeps its tuning-only declarations in one #ifdef VG_TUNING block"
+    text = m.group(1) if tuning else text[:m.start()] + text[m.end():]
     return sorted(set(re.findall(r"\b(vg_[A-Za-z0-9_]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():
     from disentangle_mlp_amd import _lib
     assert declared_symbols() == sorted(_lib.SIGNATURES)
+    assert declared_symbols(tuning=True) == sorted(_lib.TUNING_SIGNATURES)
+    assert all(n.startswith("vg_debug_") for n in _lib.TUNING_SIGNATURES)
 
 
 def test_library_exports_every_declared_symbol(lib_path):
     lib = ctypes.CDLL(lib_path)
     for name in declared_symbols():
         assert getattr(lib, name) is not None, name
+
+
+def test_product_library_has_no_tuning_knobs(lib_path):
+    """include/vaegan_hip.h promises "no global mutable state": the vg_debug_* setters (and the globals behind
+    them) are compiled only into the tuning twin, which exports the whole product ABI as well."""
+    from disentangle_mlp_amd import _lib
+    lib = ctypes.CDLL(lib_path)
+    for name in declared_symbols(tuning=True):
+        assert not hasattr(lib, name), name
+    tun = ctypes.CDLL(_lib.TUNING_LIB_PATH)
+    for name in declared_symbols() + declared_symbols(tuning=True):
+        assert getattr(tun, name) is not None, name
 
 
 def test_pure_host_entry_points(lib_path):
@@ -45,6 +64,11 @@ def test_pure_host_entry_points(lib_path):
     assert lib.vg_conv5x5_fwd(None, None, None, None, 1, 1, 8, 8, 1, 2, None) == -1
     assert lib.vg_convT5x5_fwd(None, None, None, None, 1, 1, 8, 8, 1, 2, None) == -1
     assert lib.vg_bce_loss(None, 0.9, None, None, 4, 4.0, 1.0, None) == -1
+    # split-bf16 convolutions: K-split workspaces are sized on the host (conv_ring.hip's plan)
+    assert lib.vg_conv5x5_fwd_bf16split_workspace_bytes(128, 128, 32, 32, 256, 2) == 0          # 256 tiles: no split
+    assert lib.vg_conv5x5_fwd_bf16split_workspace_bytes(128, 256, 16, 16, 256, 2) == 4 * 128 * 256 * 8 * 8 * 4
+    assert lib.vg_convT5x5_fwd_bf16split_workspace_bytes(128, 256, 16, 16, 128, 2) == 0
+    assert lib.vg_conv5x5_packed_bf16split_bytes(256, 128, 3) == (8 * 25 + 3) * 2 * 3 * 256 * 16
 
 
 def test_ops_refuse_cpu_tensors():
@@ -57,6 +81,7 @@ def test_ops_refuse_cpu_tensors():
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from disentangle_mlp_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_product", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError, match="no CPU fallback"):
         _lib.load()

@@ -36,6 +36,23 @@ def conv_arith(request, H):
 
 
 @pytest.fixture
+def tuning(H):
+    """Routes the ops through libvaegan_hip_tuning.so (same kernels + the vg_debug_* tile-forcing knobs, which the
+    product library does not have) for one test; every knob is back on its heuristic afterwards."""
+    from disentangle_mlp_amd import _lib
+    with _lib.use_tuning() as lib:
+        try:
+            yield lib
+        finally:
+            lib.vg_debug_set_conv_tile(0, -1)
+            lib.vg_debug_set_conv_tile(1, -1)
+            lib.vg_debug_set_conv_bf16split_tile(-1)
+            lib.vg_debug_set_conv_ring_tile(-1)
+            lib.vg_debug_set_wgrad(0, -1)
+            lib.vg_debug_set_wgrad(1, -1)
+
+
+@pytest.fixture
 def fp32_arith(H):
     """Tests of the fp32 implicit-GEMM kernels themselves (tile variants, packed filters)."""
     prev, H.CONV_ARITH = H.CONV_ARITH, "fp32"
@@ -248,11 +265,10 @@ def test_rejects_cpu_tensors(H):
 
 
 @pytest.mark.parametrize("variant", range(8))
-def test_every_tile_variant(H, fp32_arith, variant):
+def test_every_tile_variant(H, fp32_arith, tuning, variant):
     """The dispatcher picks tiles by grid size; force each of the 8 tile variants of the
     implicit-GEMM kernels (forward and transposed) on shapes that exercise partial tiles."""
-    from disentangle_mlp_amd import _lib
-    lib = _lib.load()
+    lib = tuning
     try:
         for (B, Cin, Cout, Hs, Ws) in ((3, 10, 70, 16, 24), (5, 6, 33, 8, 8), (2, 4, 140, 40, 72)):
             x, w = _rand(B, Cin, Hs, Ws, seed=40), 0.1 * _rand(Cout, Cin, 5, 5, seed=41)
@@ -372,11 +388,10 @@ def test_conv_random_shapes(H, conv_arith):
 @pytest.mark.parametrize("B,Cin,Cout,Hs,Ws,stride", [
     (3, 3, 32, 16, 16, 1), (2, 32, 128, 32, 32, 2), (2, 5, 130, 9, 13, 2), (2, 70, 33, 8, 8, 1),
     (1, 256, 256, 8, 8, 2)])
-def test_packed_filters_bit_identical(H, fp32_arith, B, Cin, Cout, Hs, Ws, stride):
+def test_packed_filters_bit_identical(H, fp32_arith, tuning, B, Cin, Cout, Hs, Ws, stride):
     """vg_conv5x5_fwd_packed / vg_convT5x5_fwd_packed walk K in the same order as the plain
     entry points: results must be bit-identical on every tile variant."""
-    from disentangle_mlp_amd import _lib
-    lib = _lib.load()
+    lib = tuning
     g = torch.Generator().manual_seed(5)
     x = torch.randn(B, Cin, Hs, Ws, generator=g).cuda()
     w = (torch.randn(Cout, Cin, 5, 5, generator=g) * 0.05).cuda()
@@ -476,11 +491,11 @@ def test_conv_fwd_bf16x3_falls_back_when_cin_not_multiple_of_16(H):
 @pytest.mark.parametrize("B,Cin,Cout,Hs,Ws,stride", [
     (3, 16, 32, 8, 8, 2), (2, 256, 128, 16, 16, 2), (2, 128, 32, 32, 32, 2), (5, 48, 70, 7, 5, 2),
     (3, 16, 130, 9, 12, 1), (1, 256, 256, 8, 8, 2), (4, 64, 40, 8, 8, 1), (2, 32, 3, 16, 16, 2)])
-def test_convT_fwd_bf16x3(H, B, Cin, Cout, Hs, Ws, stride):
+def test_convT_fwd_bf16x3(H, tuning, B, Cin, Cout, Hs, Ws, stride):
     """Transposed convolution (and so the data gradient of the convolutions) in the opt-in bf16x3 mode,
-    every tile variant: 2e-5 relative L2 against the fp64 oracle."""
-    from disentangle_mlp_amd import _lib
-    lib = _lib.load()
+    every tile variant of both kernel families (stride 2 with more than 64 output channels runs the ring kernel of
+    conv_ring.hip, the rest conv_bf16split.hip): 2e-5 relative L2 against the fp64 oracle."""
+    lib = tuning
     g = torch.Generator().manual_seed(10)
     x = torch.randn(B, Cin, Hs, Ws, generator=g)
     w = torch.randn(Cin, Cout, 5, 5, generator=g) * 0.05
@@ -492,14 +507,16 @@ def test_convT_fwd_bf16x3(H, B, Cin, Cout, Hs, Ws, stride):
         for variant in (-1, 0, 1, 2, 3, 4, 5):
             lib.vg_debug_set_conv_bf16split_tile(variant)
             assert_close(H.convT5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), stride), ref, 2e-5, f"bf16x3 convT tile {variant}")
+        lib.vg_debug_set_conv_bf16split_tile(-1)
+        for variant in (0, 1, 2, 3):
+            lib.vg_debug_set_conv_ring_tile(variant)
+            assert_close(H.convT5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), stride), ref, 2e-5, f"bf16x3 convT ring tile {variant}")
     finally:
         H.CONV_ARITH = prev_arith
-        lib.vg_debug_set_conv_bf16split_tile(-1)
 
 
-def test_conv_fwd_bf16x3_every_tile(H):
-    from disentangle_mlp_amd import _lib
-    lib = _lib.load()
+def test_conv_fwd_bf16x3_every_tile(H, tuning):
+    lib = tuning
     prev_arith = H.CONV_ARITH
     try:
         H.CONV_ARITH = "bf16x3"
@@ -509,9 +526,13 @@ def test_conv_fwd_bf16x3_every_tile(H):
             for variant in (0, 1, 2, 3, 5):
                 lib.vg_debug_set_conv_bf16split_tile(variant)
                 assert_close(H.conv5x5_fwd(x.cuda(), w.cuda(), None, s), ref, 2e-5, f"bf16x3 fwd tile {variant}")
+            lib.vg_debug_set_conv_bf16split_tile(-1)
+            for variant in (0, 1, 2):          # stride 2: the ring kernel's tiles
+                lib.vg_debug_set_conv_ring_tile(variant)
+                assert_close(H.conv5x5_fwd(x.cuda(), w.cuda(), None, s), ref, 2e-5, f"bf16x3 fwd ring tile {variant}")
+            lib.vg_debug_set_conv_ring_tile(-1)
     finally:
         H.CONV_ARITH = prev_arith
-        lib.vg_debug_set_conv_bf16split_tile(-1)
 
 
 @pytest.mark.parametrize("B,Cin,Cout,Hs,Ws,stride", [

@@ -331,10 +331,16 @@ def test_hip_adam_matches_torch_adam_and_shares_checkpoints(T):
 
 
 # ------------------------------------------------------------------ parity AWAY from the initial weights
-def _trained_oracle(k_iters, batch, seed=31):
-    """The oracle trained for k iterations on the host (fp32, lr 1e-3, the reference's schedule)."""
+def _trained_oracle(k_iters, batch, seed=31, lr=3e-4):
+    """The oracle trained for k iterations on the host (fp32, the reference's schedule).  lr 3e-4 rather than the
+    reference's 1e-3: on synthetic images D saturates to D(x) = 1.0f within three lr = 1e-3 iterations (fp32
+    sigmoid; the BCE then sits on its -100 clamp, where fp32 and fp64 differ by construction and the
+    gradients vanish) -- the point here is a set of weights, Adam moments and BatchNorm statistics away from
+    the initial ones, not that regime."""
     torch.set_num_threads(16)
     eg, d, oeg, od = osteps.build_nets()
+    for o in (oeg, od):
+        o.param_groups[0]["lr"] = lr
     g = torch.Generator().manual_seed(seed)
     base = torch.randn(4 * batch, 3, 8, 8, generator=g)
     data = torch.tanh(torch.nn.functional.interpolate(base, size=64, mode="bilinear"))     # smooth "images"
@@ -385,6 +391,7 @@ def test_gradients_at_trained_weights_vs_oracle(T):
     out = tr.step(x.cuda(), no.cuda(), e2.cuda(), e3.cuda(),
                   grad_hook=lambda ph, net: got_g.__setitem__(
                       ph, {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}))
+    assert 0.02 < ref_l["D_x"] < 0.98, ref_l["D_x"]            # not saturated: the comparison means something
     for k in ("errD_real", "errD_fake", "errG_fake", "errG_recon", "sim", "mse_dec", "kld", "mse_enc"):
         assert close(float(out[k]), ref_l[k], 1e-4, 1e-7), (k, float(out[k]), ref_l[k])
     worst = {}
