@@ -78,6 +78,7 @@ int vg_internal_ring_conv(int mode, const float* x, const void* packed, const fl
                           int W, int Cout, int planes, void* workspace, size_t workspace_bytes, hipStream_t st);
 #ifdef VG_TUNING
 void vg_internal_ring_set_variant(int v);
+void vg_internal_wx_set_rounds(int r);
 #endif
 int vg_internal_convT_s1_thin(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H,
                               int W, int Cout, hipStream_t st);

@@ -27,20 +27,7 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
-constexpr int WNT = 256, WTW = 8, WCIT = 5, WTM = 128;
-
-// NP planes; the pixel tile of a chunk is WTH x 8 with WTH = 4 (2 planes) or 2 (3 planes: the patch is 1.5x
-// bigger per pixel and two workgroups must still share a CU's LDS)
-template <int S_, int NP_>
-struct WX {
-  static constexpr int S = S_, NP = NP_, WTH = (NP_ == 3) ? 2 : 4;
-  static constexpr int PH = S * (WTH - 1) + 5, PW = S * (WTW - 1) + 5;
-  static constexpr int ROWU = PW + ((5 - PW % 16) + 16) % 16;                    // = 5 (mod 16)
-  static constexpr int CIU = PH * ROWU + ((9 - (PH * ROWU) % 16) + 16) % 16;     // = 9 (mod 16)
-  static constexpr int KBU = WCIT * CIU;                                          // units per (plane, k-block)
-  static constexpr int NUNIT = 2 * NP * WCIT * PH * PW;
-  static constexpr int NQ = cdiv(NUNIT, WNT);
-};
+constexpr int WTW = 8, WCIT = 5;
 
 struct WXArgs {
   const bf16x8* xp;
@@ -130,17 +117,42 @@ __global__ __launch_bounds__(256) void relayout_gy_kernel(const float* __restric
   }
 }
 
+// ---- the weight-gradient kernel: one workgroup of 8 wavefronts per CU ------------------------------------------
+// Output tile = TCO cout x 5 input channels (125 of 128 columns); WCO wavefronts along cout (32 rows each, so every
+// wavefront streams ONLY its own gy rows, global -> register, prefetched PD pixels ahead) x WN = 8 / WCO column
+// groups of 128 / WN columns.  A chunk = 16 images x (1 x 8) output pixels: its x patch [plane][k-block][5 ci]
+// [5 rows][S*7+5 cols] (50 KB for 3 planes) is double-buffered in LDS -- the next chunk's units are loaded into
+// registers at the first pixel of a chunk and written at its sixth, ONE barrier per chunk -- so the MFMAs never
+// wait for a copy.  (The 4-wavefront predecessor staged the patch between two barriers and prefetched gy one
+// pixel ahead: 142 TFLOP/s on 128 -> 256 @32 -> 16.)  Plain loads only: hipcc counts them (vmcnt) itself.
+constexpr int W8NT = 512;
+
+template <int S_, int NP_, int WCO_>
+struct W8 {
+  static constexpr int S = S_, NP = NP_, WCO = WCO_, WN = 8 / WCO_, FP = 4 / WN, TCO = 32 * WCO_;
+  // gy prefetch distance in pixels (register sets - 1): a pixel step is FP * 6 (or 3) MFMAs per wavefront, i.e. 0.35 /
+  // 0.7 us, against ~2 us for a first touch of gy from HBM; the 2-fragment tile has the registers for 8 sets
+  static constexpr int PD = (FP <= 2) ? 7 : 3;
+  static constexpr int PH = 5, PW = S * (WTW - 1) + 5;
+  static constexpr int ROWU = PW + ((5 - PW % 16) + 16) % 16;                    // = 5 (mod 16)
+  static constexpr int CIU = PH * ROWU + ((9 - (PH * ROWU) % 16) + 16) % 16;     // = 9 (mod 16)
+  static constexpr int KBU = WCIT * CIU;                                          // units per (plane, k-block)
+  static constexpr int BUFU = 2 * NP * KBU;                                       // units per patch buffer
+  static constexpr int NUNIT = 2 * NP * WCIT * PH * PW;
+  static constexpr int NQ = cdiv(NUNIT, W8NT);
+  static_assert(2 * BUFU * 16 <= 160 * 1024, "LDS");
+};
+
 template <class C>
-__global__ __launch_bounds__(WNT, 2) void conv5x5_wgrad_bf16split_kernel(WXArgs A) {
+__global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A) {
   constexpr int S = C::S, PH = C::PH, PW = C::PW, ROWU = C::ROWU, CIU = C::CIU, KBU = C::KBU, NQ = C::NQ;
-  constexpr int NP = C::NP, WTH = C::WTH;
-  __shared__ f32x4 lds[2 * NP * KBU];      // [plane][k-block][ci][row][col] x 8 images
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  constexpr int NP = C::NP, FP = C::FP, BUFU = C::BUFU, PD = C::PD;
+  __shared__ f32x4 lds[2 * BUFU];          // [buffer][plane][k-block][ci][row][col] x 8 images
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kb = lane >> 5, l32 = lane & 31;
-  const int wm = wid & 1, wn = wid >> 1;
-  // XCD-aware placement (workgroups are dealt round-robin over the 8 XCDs, each with its own L2): all output
-  // tiles of one K split -- they read the same gy / x chunks -- go to ONE XCD, so a chunk is fetched into one L2
-  // instead of eight.  Placement affects speed only.
+  const int wm = wid % C::WCO, wn = wid / C::WCO;
+  // XCD-aware placement: all output tiles of one K split read the same gy / x chunks -> one XCD (speed only)
   int bid = blockIdx.x;
   {
     const int T = A.mtiles * A.ntiles, full = (A.splits / 8) * 8 * T;
@@ -152,17 +164,16 @@ __global__ __launch_bounds__(WNT, 2) void conv5x5_wgrad_bf16split_kernel(WXArgs 
   const int mt = bid % A.mtiles;
   bid /= A.mtiles;
   const int nt = bid % A.ntiles, split = bid / A.ntiles;
-  const int m0 = mt * WTM, ci0 = nt * WCIT;
+  const int m0 = mt * C::TCO, ci0 = nt * WCIT;
   const int Cin = A.Cin, Cout = A.Cout, H = A.H, W = A.W, OW = A.OW, CoP = A.CoP;
   const int HW = H * W, P = A.OH * A.OW;
 
   // ---- staging map: unit e = (plane*2 + k-block, ci, row, col), one packed descriptor per unit
-  // (row | col << 4 | ci << 9 | pk << 12 | state << 15; state 0 = no unit, 1 = copy, 2 = channel
-  // beyond Cin -> zeros); addresses are rebuilt from it per chunk to keep registers for the tile
+  // (row | col << 4 | ci << 9 | pk << 12 | state << 15; state 0 = no unit, 1 = copy, 2 = channel beyond Cin -> zeros)
   int desc[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    const int e = tid + q * WNT;
+    const int e = tid + q * W8NT;
     const int col = e % PW;
     int t = e / PW;
     const int r = t % PH;
@@ -173,11 +184,19 @@ __global__ __launch_bounds__(WNT, 2) void conv5x5_wgrad_bf16split_kernel(WXArgs 
   }
   static_assert(PH <= 16 && PW <= 32 && WCIT <= 8, "descriptor fields");
 
+  // chunk -> (image group, output row, first output column)
+  auto chunk_pos = [&](int chunk, int& bg, int& oh, int& ow0) {
+    bg = chunk / A.tiles_hw;
+    const int sp = chunk % A.tiles_hw;
+    oh = sp / A.tiles_w;
+    ow0 = (sp % A.tiles_w) * WTW;
+  };
   f32x4 preg[NQ];
   unsigned pvalid = 0;
-  auto load_chunk = [&](int chunk) {
-    const int bg = chunk / A.tiles_hw, sp = chunk % A.tiles_hw;
-    const int ih0 = S * (sp / A.tiles_w) * WTH - 2, iw0 = S * (sp % A.tiles_w) * WTW - 2;
+  auto load_patch = [&](int chunk) {
+    int bg, oh, ow0;
+    chunk_pos(chunk, bg, oh, ow0);
+    const int ih0 = S * oh - 2, iw0 = S * ow0 - 2;
     const f32x4* src = reinterpret_cast<const f32x4*>(A.xp) + (size_t)bg * 2 * NP * Cin * HW;
     pvalid = 0;
 #pragma unroll
@@ -190,12 +209,12 @@ __global__ __launch_bounds__(WNT, 2) void conv5x5_wgrad_bf16split_kernel(WXArgs 
       preg[q] = src[(pk * Cin + min(ci0 + ci, Cin - 1)) * HW + min(max(ih, 0), H - 1) * W + min(max(iw, 0), W - 1)];
     }
   };
-  auto store_chunk = [&]() {
+  auto store_patch = [&](int buf) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int d = desc[q];
       const int state = d >> 15;
-      const int dst = ((d >> 12) & 7) * KBU + ((d >> 9) & 7) * CIU + (d & 15) * ROWU + ((d >> 4) & 31);
+      const int dst = buf * BUFU + ((d >> 12) & 7) * KBU + ((d >> 9) & 7) * CIU + (d & 15) * ROWU + ((d >> 4) & 31);
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
       if (state != 0) lds[dst] = (state == 1 && ((pvalid >> q) & 1u)) ? preg[q] : z;
     }
@@ -203,115 +222,109 @@ __global__ __launch_bounds__(WNT, 2) void conv5x5_wgrad_bf16split_kernel(WXArgs 
   static_assert(NQ <= 32, "validity mask");
 
   // ---- per-lane operand bases
-  int base_b[2];
+  int base_b[FP];
 #pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    const int n = min((wn * 2 + f) * 32 + l32, WCIT * 25 - 1);     // columns 125..127: any valid unit (result unused)
+  for (int f = 0; f < FP; ++f) {
+    const int n = min((wn * FP + f) * 32 + l32, WCIT * 25 - 1);     // columns 125..127: any valid unit (result unused)
     const int ci = n / 25, tap = n % 25;
     base_b[f] = kb * KBU + ci * CIU + (tap / 5) * ROWU + tap % 5;
   }
-  const bf16x8* ga[2];
-#pragma unroll
-  for (int g = 0; g < 2; ++g) ga[g] = A.gp + (size_t)kb * CoP + m0 + (wm * 2 + g) * 32 + l32;
-  const size_t gstep = (size_t)2 * NP * CoP;     // units per pixel
+  const bf16x8* ga = A.gp + (size_t)kb * CoP + m0 + wm * 32 + l32;     // this lane's cout row, k-block
+  const size_t gstep = (size_t)2 * NP * CoP;                           // units per pixel
 
-  f32x16 acc[2][2];
+  f32x16 acc[FP];
 #pragma unroll
-  for (int g = 0; g < 2; ++g)
+  for (int f = 0; f < FP; ++f)
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[g][f][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
 
   const int c_begin = split * A.chunks_per_split;
   const int c_end = min(c_begin + A.chunks_per_split, A.chunks);
   if (c_begin < c_end) {
+    // first pixel (in Gp) of a chunk, clamped to the last chunk of this split (prefetches past the end are unused)
+    auto chunk_pix = [&](int chunk) -> size_t {
+      int bg, oh, ow0;
+      chunk_pos(min(chunk, c_end - 1), bg, oh, ow0);
+      return (size_t)bg * P + (size_t)oh * OW + ow0;
+    };
+    bf16x8 av[PD + 1][NP];      // gy fragments of pixels t .. t+PD, ring indexed by (pixel & PD) (PD + 1 = 4 sets)
+    static_assert((PD == 3 || PD == 7) && WTW == 8, "ring indices below assume 4 or 8 sets, 8 pixels per chunk");
+    auto load_a = [&](int set, size_t pix) {
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) av[set][pl] = ga[pix * gstep + (size_t)pl * 2 * CoP];
+    };
+    load_patch(c_begin);
+    store_patch(0);
+    size_t pcur = chunk_pix(c_begin);
+#pragma unroll
+    for (int t = 0; t < PD; ++t) load_a(t, pcur + t);
+    __syncthreads();
     for (int ch = c_begin; ch < c_end; ++ch) {
-      // the patch is staged without a register prefetch across the MFMA phase (17 x 16 bytes per thread
-      // would not fit next to the tile); the CU's second workgroup computes while this one copies
-      load_chunk(ch);
-      store_chunk();
-      __syncthreads();
-      const int bg = ch / A.tiles_hw, sp = ch % A.tiles_hw;
-      const int th0 = (sp / A.tiles_w) * WTH, tw0 = (sp % A.tiles_w) * WTW;
-      bf16x8 av[2][2][NP];      // [buffer][fragment][plane]
-      {
-        const size_t p = (size_t)bg * P + (size_t)th0 * OW + tw0;
+      const int buf = (ch - c_begin) & 1;
+      const bool more = (ch + 1) < c_end;
+      const size_t pnxt = chunk_pix(ch + 1);
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+      for (int t = 0; t < WTW; ++t) {
+        // gy fragments PD pixels ahead (the last PD pixels of a chunk fetch the first ones of the next chunk)
+        load_a((t + PD) & PD, (t + PD < WTW) ? pcur + t + PD : pnxt + (t + PD - WTW));     // PD = 7: always the next chunk
+        if (t == 0 && more) load_patch(ch + 1);
+        bf16x8 bv[FP][NP];
 #pragma unroll
-          for (int pl = 0; pl < NP; ++pl) av[0][g][pl] = ga[g][p * gstep + (size_t)pl * 2 * CoP];
-      }
-#pragma unroll 1
-      for (int ph = 0; ph < WTH; ++ph) {
-        const size_t prow = (size_t)bg * P + (size_t)(th0 + ph) * OW + tw0;
-        const size_t pnext = (ph + 1 < WTH) ? prow + OW : prow;        // first pixel of the next tile row
-        const int brow = S * ph * ROWU;
+        for (int f = 0; f < FP; ++f)
 #pragma unroll
-        for (int pw = 0; pw < WTW; ++pw) {
-          const int cur = pw & 1, nxt = cur ^ 1;
-          const size_t pn = (pw + 1 < WTW) ? prow + pw + 1 : pnext;
+          for (int pl = 0; pl < NP; ++pl)
+            bv[f][pl] = __builtin_bit_cast(bf16x8, lds[buf * BUFU + base_b[f] + S * t + pl * 2 * KBU]);
+        // products with plane index sum < NP, smallest terms first, product-major
 #pragma unroll
-          for (int g = 0; g < 2; ++g)
+        for (int sum = NP - 1; sum >= 0; --sum)
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) av[nxt][g][pl] = ga[g][pn * gstep + (size_t)pl * 2 * CoP];
-          bf16x8 bv[2][NP];
+          for (int pa = sum; pa >= 0; --pa)
 #pragma unroll
-          for (int f = 0; f < 2; ++f)
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl) bv[f][pl] = __builtin_bit_cast(bf16x8, lds[base_b[f] + brow + S * pw + pl * 2 * KBU]);
-          __builtin_amdgcn_sched_barrier(0);   // keep the next pixel's gy loads ahead of this pixel's MFMAs
-          // products with plane index sum < NP, smallest terms first, product-major
-#pragma unroll
-          for (int sum = NP - 1; sum >= 0; --sum)
-#pragma unroll
-            for (int pa = sum; pa >= 0; --pa)
-#pragma unroll
-              for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int f = 0; f < 2; ++f) acc[g][f] = mfma_bf16(av[cur][g][pa], bv[f][sum - pa], acc[g][f]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
+            for (int f = 0; f < FP; ++f) acc[f] = mfma_bf16(av[t & PD][pa], bv[f][sum - pa], acc[f]);
+        if (t == 5 && more) store_patch(buf ^ 1);      // the other buffer was last read in the previous chunk
       }
       __syncthreads();
+      pcur = pnxt;
     }
   }
 
   // ---- partial slab: ws[split][co][ci*25 + tap]
   float* wsb = A.ws + (size_t)split * Cout * Cin * 25;
 #pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    const int n = (wn * 2 + f) * 32 + l32;
+  for (int f = 0; f < FP; ++f) {
+    const int n = (wn * FP + f) * 32 + l32;
     const bool nok = n < WCIT * 25 && (ci0 + n / 25) < Cin;
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int r16 = 0; r16 < 16; ++r16) {
-        const int co = m0 + (wm * 2 + g) * 32 + acc_row(r16, lane);
-        if (nok && co < Cout) wsb[((size_t)co * Cin + ci0) * 25 + n] = acc[g][f][r16];
-      }
+    for (int r16 = 0; r16 < 16; ++r16) {
+      const int co = m0 + wm * 32 + acc_row(r16, lane);
+      if (nok && co < Cout) wsb[((size_t)co * Cin + ci0) * 25 + n] = acc[f][r16];
+    }
   }
 }
 
 struct XPlan {
-  int BG, CoP, OH, OW, mtiles, ntiles, tiles_w, tiles_hw, chunks, cps, splits;
+  int BG, CoP, OH, OW, wco, mtiles, ntiles, tiles_w, tiles_hw, chunks, cps, splits;
   size_t xp_bytes, gp_bytes, slab_bytes;
 };
 
+VG_KNOB(int, g_wx_rounds, 1);     // tuning build: workgroups per CU the K split aims at
+
 bool make_xplan(int B, int Cin, int H, int W, int Cout, int S, int planes, XPlan& p) {
-  const int wth = planes == 3 ? 2 : 4;
   p.OH = (H - 1) / S + 1;
   p.OW = (W - 1) / S + 1;
-  if (p.OH % wth || p.OW % WTW) return false;          // whole pixel tiles only (caller falls back to fp32)
+  if (p.OW % WTW) return false;                         // whole 1 x 8 pixel tiles only (caller falls back to fp32)
   p.BG = cdiv(B, 16);
   p.CoP = (Cout + 127) & ~127;
-  p.mtiles = cdiv(Cout, WTM);
+  p.wco = Cout > 128 ? 8 : 4;                           // wavefronts along cout: 256- or 128-row output tiles
+  p.mtiles = cdiv(Cout, 32 * p.wco);
   p.ntiles = cdiv(Cin, WCIT);
   p.tiles_w = p.OW / WTW;
-  p.tiles_hw = p.tiles_w * (p.OH / wth);
+  p.tiles_hw = p.tiles_w * p.OH;
   p.chunks = p.BG * p.tiles_hw;
+  // K split: one workgroup per CU and (just under) one round of them -- every workgroup does the same work, and
+  // each extra split is one more slab (Cout x Cin x 25 floats) to write and sum
   const int tiles = p.mtiles * p.ntiles;
-  int want = cdiv(tiles >= 32 ? 2048 : 1024, tiles);
+  int want = (256 * g_wx_rounds) / tiles;
   if (want > p.chunks) want = p.chunks;
   if (want < 1) want = 1;
   p.cps = cdiv(p.chunks, want);
@@ -324,12 +337,21 @@ bool make_xplan(int B, int Cin, int H, int W, int Cout, int S, int planes, XPlan
 
 template <class C>
 int launch_wx(const WXArgs& A, long grid, hipStream_t st) {
-  hipLaunchKernelGGL(conv5x5_wgrad_bf16split_kernel<C>, dim3((unsigned)grid), dim3(WNT), 0, st, A);
+  hipLaunchKernelGGL(conv5x5_wgrad_split8_kernel<C>, dim3((unsigned)grid), dim3(W8NT), 0, st, A);
   VG_CHECK_LAUNCH();
   return 0;
 }
 
+template <int S, int NP>
+int launch_wx_by_cout(const WXArgs& A, int wco, long grid, hipStream_t st) {
+  return wco == 8 ? launch_wx<W8<S, NP, 8>>(A, grid, st) : launch_wx<W8<S, NP, 4>>(A, grid, st);
+}
+
 }  // namespace
+
+#ifdef VG_TUNING
+void vg_internal_wx_set_rounds(int r) { g_wx_rounds = r > 0 ? r : 1; }
+#endif
 
 extern "C" size_t vg_conv5x5_wgrad_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride,
                                                           int planes) {
@@ -374,8 +396,8 @@ extern "C" int vg_conv5x5_wgrad_bf16split(const float* x, const float* gy, float
   const long grid = (long)p.mtiles * p.ntiles * p.splits;
   if (grid > 0x7fffffffL) return VG_ERR_BAD_ARG;
   int rc;
-  if (planes == 2) rc = (stride == 2) ? launch_wx<WX<2, 2>>(A, grid, st) : launch_wx<WX<1, 2>>(A, grid, st);
-  else rc = (stride == 2) ? launch_wx<WX<2, 3>>(A, grid, st) : launch_wx<WX<1, 3>>(A, grid, st);
+  if (planes == 2) rc = (stride == 2) ? launch_wx_by_cout<2, 2>(A, p.wco, grid, st) : launch_wx_by_cout<1, 2>(A, p.wco, grid, st);
+  else rc = (stride == 2) ? launch_wx_by_cout<2, 3>(A, p.wco, grid, st) : launch_wx_by_cout<1, 3>(A, p.wco, grid, st);
   if (rc) return rc;
   return vg_internal_wgrad_reduce(slabs, dw, Cout * Cin * 25, p.splits, st);
 }

@@ -562,8 +562,9 @@ def test_conv_wgrad_bf16x3_unsupported_shape_falls_back(H):
     lib = _lib.load()
     assert lib.vg_conv5x5_wgrad_bf16split_workspace_bytes(4, 8, 10, 10, 8, 2, 2) == 0     # 5 x 5 outputs
     assert lib.vg_conv5x5_wgrad_bf16split_workspace_bytes(4, 8, 16, 16, 8, 2, 2) > 0
-    assert lib.vg_conv5x5_wgrad_bf16split_workspace_bytes(4, 8, 12, 16, 8, 2, 3) > 0      # 6 x 8 outputs: 3 planes tile 2 x 8
-    assert lib.vg_conv5x5_wgrad_bf16split_workspace_bytes(4, 8, 12, 16, 8, 2, 2) == 0
+    assert lib.vg_conv5x5_wgrad_bf16split_workspace_bytes(4, 8, 12, 16, 8, 2, 3) > 0      # 6 x 8 outputs: rows of 1 x 8 pixel tiles
+    assert lib.vg_conv5x5_wgrad_bf16split_workspace_bytes(4, 8, 12, 16, 8, 2, 2) > 0
+    assert lib.vg_conv5x5_wgrad_bf16split_workspace_bytes(4, 8, 12, 12, 8, 2, 3) == 0      # 6 outputs per row: not a multiple of 8
     x, gy = _rand(2, 3, 10, 10, seed=3), _rand(2, 4, 5, 5, seed=4)
     w = 0.1 * _rand(4, 3, 5, 5, seed=5)
     prev_arith = H.CONV_ARITH
