@@ -305,7 +305,18 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
         if (n == pr) { pa = a; pb = sum - a; }
         ++n;
       }
-    acc[g][f] = mfma_bf16(av[buf][g][pa], bv[buf][f][pb], acc[g][f]);
+    if constexpr ((abl & 128) != 0) {
+      // timing experiment: the same FLOPs as two v_mfma_f32_16x16x32_bf16 (numerically meaningless here)
+      typedef float f32x4v __attribute__((ext_vector_type(4)));
+      f32x4v c0 = {acc[g][f][0], acc[g][f][1], acc[g][f][2], acc[g][f][3]};
+      f32x4v c1 = {acc[g][f][4], acc[g][f][5], acc[g][f][6], acc[g][f][7]};
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[buf][g][pa], bv[buf][f][pb], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[buf][g][pa], bv[buf][f][pb], c1, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { acc[g][f][r] = c0[r]; acc[g][f][4 + r] = c1[r]; }
+    } else {
+      acc[g][f] = mfma_bf16(av[buf][g][pa], bv[buf][f][pb], acc[g][f]);
+    }
   };
   // a step's MFMAs with the next step's fragment reads spread between them (one read per RS MFMAs), pinned
   constexpr int RS = (NMF / NRD) > 0 ? (NMF / NRD) : 1;

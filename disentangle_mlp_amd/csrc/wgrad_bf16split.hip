@@ -9,9 +9,10 @@
 // GEMM view: D[co][n = ci*25 + tap], reduction over (image, output pixel).  The bf16 MFMA wants 8
 // consecutive k per lane; "consecutive pixels" would make the patch operand an unaligned 16-byte
 // LDS read, so k runs over IMAGES: one MFMA step = one output pixel x 16 images (k-block 0 / 1 =
-// images 0-7 / 8-15).  Two re-layout passes put both operands batch-innermost, split into hi / lo:
-//   Xp[image group][plane][k-block][ci][h][w]   x 8 images (16 B)   <- x
-//   Gp[image group][pixel][plane][k-block][co]  x 8 images (16 B)   <- gy   (LDS transpose)
+// images 0-7 / 8-15).  Both operands must therefore be batch-innermost and split into planes:
+//   gy: one re-layout pass -> Gp[image group][pixel][plane][k-block][co] x 8 images (16 B)   (LDS transpose);
+//   x : no pass -- the kernel stages its patch straight from NCHW (8 loads an image apart per unit) and splits it
+//       while it writes it to LDS.
 // The kernel (4 wavefronts, 128 co x 5 ci (125 of 128 columns), 2 x 2 fragments per wavefront):
 //   * per chunk = (image group, 4 x 8 output pixels) the x patch [plane][k-block][5 ci][rows][cols]
 //     is copied to LDS as 16-byte units; MFMA column n reads unit (ci, S*oh+kh, S*ow+kw) at a
@@ -30,7 +31,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 constexpr int WTW = 8, WCIT = 5;
 
 struct WXArgs {
-  const bf16x8* xp;
+  const float* x;      // NCHW fp32 (the patch is split while it is staged)
+  int B;
   const bf16x8* gp;
   float* ws;
   int Cin, H, W, Cout, CoP, OH, OW;
@@ -53,28 +55,6 @@ __device__ __forceinline__ void split_planes(float* v, bf16x8* out) {
       out[p][j] = h;
       v[j] -= (float)h;
     }
-  }
-}
-
-// ---- x[B][C][HW] -> Xp[bg][plane][kb][C][HW] x 8 images
-template <int NP>
-__global__ __launch_bounds__(256) void relayout_x_kernel(const float* __restrict__ x, bf16x8* __restrict__ xp, int B,
-                                                        size_t chw) {
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const int bg = blockIdx.y;
-  if (e >= chw) return;
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int b = bg * 16 + kb * 8 + j;
-      v[j] = b < B ? x[(size_t)b * chw + e] : 0.f;
-    }
-    bf16x8 pl[NP];
-    split_planes<NP>(v, pl);
-#pragma unroll
-    for (int p = 0; p < NP; ++p) xp[(((size_t)bg * NP + p) * 2 + kb) * chw + e] = pl[p];
   }
 }
 
@@ -138,7 +118,7 @@ struct W8 {
   static constexpr int CIU = PH * ROWU + ((9 - (PH * ROWU) % 16) + 16) % 16;     // = 9 (mod 16)
   static constexpr int KBU = WCIT * CIU;                                          // units per (plane, k-block)
   static constexpr int BUFU = 2 * NP * KBU;                                       // units per patch buffer
-  static constexpr int NUNIT = 2 * NP * WCIT * PH * PW;
+  static constexpr int NUNIT = 2 * WCIT * PH * PW;          // staged units (k-block, ci, row, col): 8 images each
   static constexpr int NQ = cdiv(NUNIT, W8NT);
   static_assert(2 * BUFU * 16 <= 160 * 1024, "LDS");
 };
@@ -168,8 +148,10 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
   const int Cin = A.Cin, Cout = A.Cout, H = A.H, W = A.W, OW = A.OW, CoP = A.CoP;
   const int HW = H * W, P = A.OH * A.OW;
 
-  // ---- staging map: unit e = (plane*2 + k-block, ci, row, col), one packed descriptor per unit
-  // (row | col << 4 | ci << 9 | pk << 12 | state << 15; state 0 = no unit, 1 = copy, 2 = channel beyond Cin -> zeros)
+  // ---- staging map: unit e = (k-block, ci, row, col) = 8 images of one input pixel, read straight from x (NCHW
+  // fp32: 8 loads a channel-image apart), split into the NP planes in registers and written as NP 16-byte LDS units.
+  // One packed descriptor per unit: row | col << 4 | ci << 9 | kb << 12 | state << 13 (state 0 = no unit, 1 = copy,
+  // 2 = channel beyond Cin -> zeros).
   int desc[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
@@ -178,9 +160,9 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
     int t = e / PW;
     const int r = t % PH;
     t /= PH;
-    const int ci = t % WCIT, pk = min(t / WCIT, 2 * NP - 1);
+    const int ci = t % WCIT, kbs = min(t / WCIT, 1);
     const int state = e < C::NUNIT ? ((ci0 + ci) < Cin ? 1 : 2) : 0;
-    desc[q] = r | (col << 4) | (ci << 9) | (pk << 12) | (state << 15);
+    desc[q] = r | (col << 4) | (ci << 9) | (kbs << 12) | (state << 13);
   }
   static_assert(PH <= 16 && PW <= 32 && WCIT <= 8, "descriptor fields");
 
@@ -191,32 +173,47 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
     oh = sp / A.tiles_w;
     ow0 = (sp % A.tiles_w) * WTW;
   };
-  f32x4 preg[NQ];
+  float preg[NQ][8];
   unsigned pvalid = 0;
+  const size_t chw = (size_t)Cin * HW;
   auto load_patch = [&](int chunk) {
     int bg, oh, ow0;
     chunk_pos(chunk, bg, oh, ow0);
     const int ih0 = S * oh - 2, iw0 = S * ow0 - 2;
-    const f32x4* src = reinterpret_cast<const f32x4*>(A.xp) + (size_t)bg * 2 * NP * Cin * HW;
     pvalid = 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int d = desc[q];
       const int ih = ih0 + (d & 15), iw = iw0 + ((d >> 4) & 31);
-      const int ci = (d >> 9) & 7, pk = (d >> 12) & 7;
+      const int ci = (d >> 9) & 7, kbs = (d >> 12) & 1;
       const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
       pvalid |= ok ? (1u << q) : 0u;
-      preg[q] = src[(pk * Cin + min(ci0 + ci, Cin - 1)) * HW + min(max(ih, 0), H - 1) * W + min(max(iw, 0), W - 1)];
+      const unsigned off = (unsigned)(min(ci0 + ci, Cin - 1) * HW + min(max(ih, 0), H - 1) * W + min(max(iw, 0), W - 1));
+      const int b0 = bg * 16 + kbs * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float* xb = A.x + (size_t)min(b0 + j, A.B - 1) * chw;      // images past the batch: clamped, zeroed below
+        preg[q][j] = xb[off];
+      }
     }
   };
-  auto store_patch = [&](int buf) {
+  auto store_patch = [&](int buf, int chunk) {
+    const int bgrp = chunk / A.tiles_hw;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int d = desc[q];
-      const int state = d >> 15;
-      const int dst = buf * BUFU + ((d >> 12) & 7) * KBU + ((d >> 9) & 7) * CIU + (d & 15) * ROWU + ((d >> 4) & 31);
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      if (state != 0) lds[dst] = (state == 1 && ((pvalid >> q) & 1u)) ? preg[q] : z;
+      const int state = d >> 13, kbs = (d >> 12) & 1;
+      const bool live = state == 1 && ((pvalid >> q) & 1u);
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (live && (bgrp * 16 + kbs * 8 + j) < A.B) ? preg[q][j] : 0.f;
+      bf16x8 pl[NP];
+      split_planes<NP>(v, pl);
+      const int dst = buf * BUFU + kbs * KBU + ((d >> 9) & 7) * CIU + (d & 15) * ROWU + ((d >> 4) & 31);
+      if (state != 0) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) lds[dst + p * 2 * KBU] = __builtin_bit_cast(f32x4, pl[p]);
+      }
     }
   };
   static_assert(NQ <= 32, "validity mask");
@@ -254,7 +251,7 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
       for (int pl = 0; pl < NP; ++pl) av[set][pl] = ga[pix * gstep + (size_t)pl * 2 * CoP];
     };
     load_patch(c_begin);
-    store_patch(0);
+    store_patch(0, c_begin);
     size_t pcur = chunk_pix(c_begin);
 #pragma unroll
     for (int t = 0; t < PD; ++t) load_a(t, pcur + t);
@@ -281,7 +278,7 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
           for (int pa = sum; pa >= 0; --pa)
 #pragma unroll
             for (int f = 0; f < FP; ++f) acc[f] = mfma_bf16(av[t & PD][pa], bv[f][sum - pa], acc[f]);
-        if (t == 5 && more) store_patch(buf ^ 1);      // the other buffer was last read in the previous chunk
+        if (t == 5 && more) store_patch(buf ^ 1, ch + 1);      // the other buffer was last read in the previous chunk
       }
       __syncthreads();
       pcur = pnxt;
@@ -304,7 +301,7 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
 
 struct XPlan {
   int BG, CoP, OH, OW, wco, mtiles, ntiles, tiles_w, tiles_hw, chunks, cps, splits;
-  size_t xp_bytes, gp_bytes, slab_bytes;
+  size_t gp_bytes, slab_bytes;
 };
 
 VG_KNOB(int, g_wx_rounds, 1);     // tuning build: workgroups per CU the K split aims at
@@ -329,7 +326,6 @@ bool make_xplan(int B, int Cin, int H, int W, int Cout, int S, int planes, XPlan
   if (want < 1) want = 1;
   p.cps = cdiv(p.chunks, want);
   p.splits = cdiv(p.chunks, p.cps);
-  p.xp_bytes = (size_t)p.BG * 2 * planes * Cin * H * W * 16;
   p.gp_bytes = (size_t)p.BG * p.OH * p.OW * 2 * planes * p.CoP * 16;
   p.slab_bytes = (size_t)p.splits * Cout * Cin * 25 * sizeof(float);
   return true;
@@ -359,7 +355,7 @@ extern "C" size_t vg_conv5x5_wgrad_bf16split_workspace_bytes(int B, int Cin, int
   if (planes != 2 && planes != 3) return 0;
   XPlan p;
   if (!make_xplan(B, Cin, H, W, Cout, stride, planes, p)) return 0;     // 0: shape not supported by this mode
-  return p.xp_bytes + p.gp_bytes + p.slab_bytes;
+  return p.gp_bytes + p.slab_bytes;
 }
 
 extern "C" int vg_conv5x5_wgrad_bf16split(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W,
@@ -369,26 +365,19 @@ extern "C" int vg_conv5x5_wgrad_bf16split(const float* x, const float* gy, float
   if ((stride != 1 && stride != 2) || (planes != 2 && planes != 3)) return VG_ERR_BAD_ARG;
   XPlan p;
   if (!make_xplan(B, Cin, H, W, Cout, stride, planes, p)) return VG_ERR_BAD_ARG;
-  if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < p.xp_bytes + p.gp_bytes + p.slab_bytes)
+  if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < p.gp_bytes + p.slab_bytes)
     return VG_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  bf16x8* xp = (bf16x8*)workspace;
-  bf16x8* gp = (bf16x8*)((char*)workspace + p.xp_bytes);
-  float* slabs = (float*)((char*)workspace + p.xp_bytes + p.gp_bytes);
-  const size_t chw = (size_t)Cin * H * W;
+  bf16x8* gp = (bf16x8*)workspace;
+  float* slabs = (float*)((char*)workspace + p.gp_bytes);
   const int P = p.OH * p.OW;
-  if (cdiv((long)chw, 256L) > 0x7fffffffL || p.BG * 2 > 65535 || p.CoP / 32 > 65535) return VG_ERR_BAD_ARG;
-  const dim3 gx((unsigned)((chw + 255) / 256), p.BG), gg(cdiv(P, 32), p.CoP / 32, p.BG * 2);
-  if (planes == 2) {
-    hipLaunchKernelGGL(relayout_x_kernel<2>, gx, dim3(256), 0, st, x, xp, B, chw);
-    hipLaunchKernelGGL(relayout_gy_kernel<2>, gg, dim3(256), 0, st, gy, gp, B, Cout, p.CoP, P);
-  } else {
-    hipLaunchKernelGGL(relayout_x_kernel<3>, gx, dim3(256), 0, st, x, xp, B, chw);
-    hipLaunchKernelGGL(relayout_gy_kernel<3>, gg, dim3(256), 0, st, gy, gp, B, Cout, p.CoP, P);
-  }
+  if ((size_t)Cin * H * W * 4 > 0xffffffffUL || p.BG * 2 > 65535 || p.CoP / 32 > 65535) return VG_ERR_BAD_ARG;
+  const dim3 gg(cdiv(P, 32), p.CoP / 32, p.BG * 2);
+  if (planes == 2) hipLaunchKernelGGL(relayout_gy_kernel<2>, gg, dim3(256), 0, st, gy, gp, B, Cout, p.CoP, P);
+  else hipLaunchKernelGGL(relayout_gy_kernel<3>, gg, dim3(256), 0, st, gy, gp, B, Cout, p.CoP, P);
   VG_CHECK_LAUNCH();
   WXArgs A;
-  A.xp = xp; A.gp = gp; A.ws = slabs;
+  A.x = x; A.B = B; A.gp = gp; A.ws = slabs;
   A.Cin = Cin; A.H = H; A.W = W; A.Cout = Cout; A.CoP = p.CoP; A.OH = p.OH; A.OW = p.OW;
   A.mtiles = p.mtiles; A.ntiles = p.ntiles; A.splits = p.splits; A.tiles_w = p.tiles_w; A.tiles_hw = p.tiles_hw;
   A.chunks = p.chunks; A.chunks_per_split = p.cps;
