@@ -26,20 +26,28 @@ SIGNATURES = {
     "vg_conv5x5_pack": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "vg_conv5x5_fwd_packed": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_convT5x5_fwd_packed": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vg_conv5x5_fwd_packed_stats_floats": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "vg_conv5x5_fwd_packed_stats": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "vg_conv5x5_packed_bf16split_bytes": (_Z, [_I, _I, _I]),
     "vg_conv5x5_pack_bf16split": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "vg_convT5x5_fwd_bf16split_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
-    "vg_convT5x5_fwd_bf16split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "vg_convT5x5_fwd_bf16split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P]),
     "vg_conv5x5_fwd_bf16split_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
-    "vg_conv5x5_fwd_bf16split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "vg_conv5x5_bf16split_fusable": (_I, [_I, _I, _I, _I]),
+    "vg_conv5x5_fwd_bf16split_stats_floats": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "vg_convT5x5_fwd_bf16split_stats_floats": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "vg_conv5x5_fwd_bf16split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P]),
     "vg_conv5x5_wgrad_bf16split_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
-    "vg_conv5x5_wgrad_bf16split": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "vg_conv5x5_wgrad_bf16split": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _I, _I, _P]),
     "vg_conv5x5_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "vg_conv5x5_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "vg_channel_sum": (_I, [_P, _P, _I, _I, _I, _P, _Z, _P]),
     "vg_bn_workspace_bytes": (_Z, [_I]),
     "vg_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P, _Z, _P]),
     "vg_bn_act_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
+    "vg_bn_finalize_stats": (_I, [_P, _I, _I, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _Z, _P]),
+    "vg_bn_stats": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _Z, _P]),
+    "vg_affine_act": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "vg_bias_act_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "vg_act_bwd": (_I, [_P, _P, _P, _Z, _I, _P]),
     "vg_reparam_kl_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
@@ -117,6 +125,12 @@ class use_tuning:
         global _lib
         _lib = self._prev
         return False
+
+
+class ConvFusion(ctypes.Structure):
+    """vg_conv_fusion of include/vaegan_hip.h."""
+    _fields_ = [("in_scale", c_void_p), ("in_shift", c_void_p), ("in_act", c_int), ("stats", c_void_p),
+                ("stats_floats", c_size_t)]
 
 
 class HipKernelError(RuntimeError):

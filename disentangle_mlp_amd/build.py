@@ -24,6 +24,9 @@ OUT_TUNING = os.path.join(HERE, "libvaegan_hip_tuning.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", f"-I{INCLUDE}", f"-I{CSRC}",
          "-Wno-unused-result"]
+# conv_ring.hip unrolls the 25 K steps of a channel chunk (compile-time tap offsets, static fragment registers):
+# past LLVM's default pragma-unroll budget the loop stays rolled and the fragment arrays go to scratch
+FILE_FLAGS = {"conv_ring.hip": ["-mllvm", "-pragma-unroll-threshold=131072"]}
 
 
 def _hipcc():
@@ -52,7 +55,7 @@ def _build_one(out, bdir_name, extra, force, verbose):
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + extra + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + extra + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -344,7 +344,168 @@ size_t ws_bytes(int C) { return part_bytes(C) + 64; }
 
 }  // namespace
 
+// Per-channel coefficients of a train-mode BatchNorm from partial sums: `part` holds, for channel c and partial k,
+// (sum, sum of squares) at part[(c * cs + k * ks) * 2 + {0, 1}] -- fp32 slots written by a convolution epilogue
+// (cs = 1... see vg_bn_finalize_stats) or the fp64 slices of bn_partial_kernel<0>.  Fixed summation order, fp64.
+// Writes mean / invstd (saved for backward), scale = gamma * invstd, shift = beta - mean * scale, and updates the
+// running statistics exactly as bn_apply_kernel's slice-0 workgroup does.
+template <typename T>
+__global__ __launch_bounds__(NT) void bn_finalize_kernel(const T* __restrict__ part, int np, long cs, long ks, int C,
+                                                         double count, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                         float* __restrict__ running_var, float* __restrict__ mean_out,
+                                                         float* __restrict__ invstd_out, float* __restrict__ scale,
+                                                         float* __restrict__ shift, float eps, float momentum) {
+  // 32 channels per workgroup x 8 partial-lanes: consecutive threads read consecutive channels (the convolution's
+  // slots are [slot][C][2]: 256 contiguous bytes per 32 threads), each partial-lane sums every 8th partial, and the 8
+  // sums of a channel are added in a fixed order
+  constexpr int CH = 32, KL = NT / CH;
+  __shared__ double r1[KL][CH], r2[KL][CH];
+  const int cl = threadIdx.x % CH, kl = threadIdx.x / CH;
+  const int c = blockIdx.x * CH + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int k = kl; k < np; k += KL) {
+      s1 += (double)part[((size_t)c * cs + (size_t)k * ks) * 2];
+      s2 += (double)part[((size_t)c * cs + (size_t)k * ks) * 2 + 1];
+    }
+  r1[kl][cl] = s1;
+  r2[kl][cl] = s2;
+  __syncthreads();
+  if (kl == 0 && c < C) {
+    s1 = 0.0;
+    s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < KL; ++k) {
+      s1 += r1[k][cl];
+      s2 += r2[k][cl];
+    }
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mu = (float)m, is = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * is;
+    mean_out[c] = mu;
+    invstd_out[c] = is;
+    scale[c] = sc;
+    shift[c] = beta[c] - mu * sc;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    if (running_var) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  }
+}
+
+// First stage for MANY slots (a 3 -> 32 first layer at B = 128 leaves 16 384 of them for 32 channels): workgroup
+// (channel block, split) sums its share of the slots into fp64 partials part[c][split][2], in a fixed order.
+__global__ __launch_bounds__(NT) void stats_partial_kernel(const float* __restrict__ stats, int nslots, int C, int nsplit,
+                                                           double* __restrict__ part) {
+  constexpr int CH = 32, KL = NT / CH;
+  __shared__ double r1[KL][CH], r2[KL][CH];
+  const int cl = threadIdx.x % CH, kl = threadIdx.x / CH;
+  const int c = blockIdx.x * CH + cl, sp = blockIdx.y;
+  const int per = cdiv(nslots, nsplit), k0 = sp * per, k1 = min(k0 + per, nslots);
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int k = k0 + kl; k < k1; k += KL) {
+      s1 += (double)stats[((size_t)k * C + c) * 2];
+      s2 += (double)stats[((size_t)k * C + c) * 2 + 1];
+    }
+  r1[kl][cl] = s1;
+  r2[kl][cl] = s2;
+  __syncthreads();
+  if (kl == 0 && c < C) {
+    s1 = 0.0;
+    s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < KL; ++k) {
+      s1 += r1[k][cl];
+      s2 += r2[k][cl];
+    }
+    part[((size_t)c * nsplit + sp) * 2] = s1;
+    part[((size_t)c * nsplit + sp) * 2 + 1] = s2;
+  }
+}
+
+// y = act(x * scale[c] + shift[c]): the normalise pass with given coefficients (layers whose consumer cannot apply
+// them while it loads)
+__global__ __launch_bounds__(NT) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, float* __restrict__ y, int C,
+                                                        int HW, size_t n4, int act) {
+  const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= n4) return;
+  const size_t e = 4 * i;
+  const int c = (int)((e / HW) % C);          // HW % 4 == 0: the four elements share a channel
+  const float sc = scale[c], sh = shift[c];
+  const float4 v = *reinterpret_cast<const float4*>(x + e);
+  float4 o;
+  o.x = act_fwd(fmaf(v.x, sc, sh), act);
+  o.y = act_fwd(fmaf(v.y, sc, sh), act);
+  o.z = act_fwd(fmaf(v.z, sc, sh), act);
+  o.w = act_fwd(fmaf(v.w, sc, sh), act);
+  *reinterpret_cast<float4*>(y + e) = o;
+}
+
 extern "C" size_t vg_bn_workspace_bytes(int C) { return C > 0 ? ws_bytes(C) : 0; }
+
+extern "C" int vg_bn_finalize_stats(const float* stats, int nslots, int C, double count, const float* gamma,
+                                    const float* beta, float* running_mean, float* running_var, float* save_mean,
+                                    float* save_invstd, float* scale, float* shift, float eps, float momentum,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  if (!stats || nslots <= 0 || C <= 0 || count <= 0 || !gamma || !beta || !save_mean || !save_invstd || !scale || !shift)
+    return VG_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  // few slots per channel block: one launch; many: NS_MAX-way first stage into the BatchNorm workspace
+  if ((long)nslots * cdiv(C, 32) <= 4096) {
+    hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(cdiv(C, 32)), dim3(NT), 0, st, stats, nslots, 1L, (long)C, C,
+                       count, gamma, beta, running_mean, running_var, save_mean, save_invstd, scale, shift, eps,
+                       momentum);      // stats[slot][C][2]: channel stride 1, slot stride C
+    VG_CHECK_LAUNCH();
+    return 0;
+  }
+  if (!workspace || workspace_bytes < ws_bytes(C)) return VG_ERR_WORKSPACE;
+  double* part = (double*)workspace;
+  hipLaunchKernelGGL(stats_partial_kernel, dim3(cdiv(C, 32), NS_MAX), dim3(NT), 0, st, stats, nslots, C, NS_MAX, part);
+  VG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, 32)), dim3(NT), 0, st, (const double*)part, NS_MAX,
+                     (long)NS_MAX, 1L, C, count, gamma, beta, running_mean, running_var, save_mean, save_invstd, scale,
+                     shift, eps, momentum);      // part[c][NS_MAX][2]
+  VG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vg_bn_stats(const float* x, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float* save_mean, float* save_invstd, float* scale, float* shift, int B,
+                           int C, int HW, float eps, float momentum, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+  if (!x || !gamma || !beta || !save_mean || !save_invstd || !scale || !shift || B <= 0 || C <= 0 || HW <= 0)
+    return VG_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < ws_bytes(C)) return VG_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  double* part = (double*)workspace;
+  const Slicing s = make_slicing(B, C, HW);
+  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(C, s.ns), dim3(NT), 0, st, x, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part, B, C, HW, s.per, s.ns, 0);
+  VG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, 32)), dim3(NT), 0, st, (const double*)part, s.ns,
+                     (long)s.ns, 1L, C, (double)B * HW, gamma, beta, running_mean, running_var, save_mean, save_invstd,
+                     scale, shift, eps, momentum);      // part[c][ns][2]
+  VG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vg_affine_act(const float* x, const float* scale, const float* shift, float* y, int B, int C, int HW,
+                             int act, void* stream) {
+  if (!x || !scale || !shift || !y || B <= 0 || C <= 0 || HW <= 0 || (HW & 3)) return VG_ERR_BAD_ARG;
+  if (act < VG_ACT_NONE || act > VG_ACT_LRELU) return VG_ERR_BAD_ARG;
+  const size_t n4 = (size_t)B * C * HW / 4;
+  if (cdiv((long)n4, (long)NT) > 0x7fffffffL) return VG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(affine_act_kernel, dim3((unsigned)((n4 + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, x, scale,
+                     shift, y, C, HW, n4, act);
+  VG_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int vg_bn_act_fwd(const float* x, const float* gamma, const float* beta, float* y, float* running_mean,
                              float* running_var, float* save_mean, float* save_invstd, int B, int C, int HW,

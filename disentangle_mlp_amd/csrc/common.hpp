@@ -74,8 +74,10 @@ __host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 int vg_internal_wgrad_reduce(const float* slabs, float* dw, int n, int splits, hipStream_t st);
 // conv_ring.hip: stride-2 split-bf16 convolution (mode 0) / transposed convolution (mode 1), 8-wave ring kernel
 size_t vg_internal_ring_workspace_bytes(int mode, int B, int Cin, int H, int W, int Cout);
+size_t vg_internal_ring_stats_floats(int mode, int B, int Cin, int H, int W, int Cout);
 int vg_internal_ring_conv(int mode, const float* x, const void* packed, const float* bias, float* y, int B, int Cin, int H,
-                          int W, int Cout, int planes, void* workspace, size_t workspace_bytes, hipStream_t st);
+                          int W, int Cout, int planes, void* workspace, size_t workspace_bytes, const float* in_scale,
+                          const float* in_shift, int in_act, float* stats, size_t stats_floats, hipStream_t st);
 #ifdef VG_TUNING
 void vg_internal_ring_set_variant(int v);
 void vg_internal_wx_set_rounds(int r);

@@ -548,13 +548,33 @@ extern "C" size_t vg_conv5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H
   return (size_t)k * B * Cout * ((H - 1) / stride + 1) * ((W - 1) / stride + 1) * sizeof(float);
 }
 
+static bool fuse_empty(const vg_conv_fusion* f) { return !f || (!f->in_scale && !f->in_shift && !f->stats); }
+
+extern "C" int vg_conv5x5_bf16split_fusable(int transposed, int Cin, int Cout, int stride) {
+  if (Cin <= 0 || Cin % 16 || Cout <= 0) return 0;
+  return transposed ? (tr_on_ring(Cout, stride) ? 1 : 0) : (stride == 2 ? 1 : 0);
+}
+
+extern "C" size_t vg_conv5x5_fwd_bf16split_stats_floats(int B, int Cin, int H, int W, int Cout, int stride) {
+  if (B <= 0 || Cin <= 0 || Cin % 16 || Cout <= 0 || H <= 0 || W <= 0 || stride != 2) return 0;
+  return vg_internal_ring_stats_floats(0, B, Cin, H, W, Cout);
+}
+
+extern "C" size_t vg_convT5x5_fwd_bf16split_stats_floats(int B, int Cin, int H, int W, int Cout, int stride) {
+  if (B <= 0 || Cin <= 0 || Cin % 16 || Cout <= 0 || H <= 0 || W <= 0 || !tr_on_ring(Cout, stride)) return 0;
+  return vg_internal_ring_stats_floats(1, B, Cin, H, W, Cout);
+}
+
 extern "C" int vg_conv5x5_fwd_bf16split(const float* x, const void* packed, const float* bias, float* y, int B, int Cin,
                                      int H, int W, int Cout, int stride, int planes, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
+                                     size_t workspace_bytes, const vg_conv_fusion* fuse, void* stream) {
   if (!x_args_ok(x, packed, y, B, Cin, H, W, Cout, stride, planes)) return VG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (stride == 2)
-    return vg_internal_ring_conv(0, x, packed, bias, y, B, Cin, H, W, Cout, planes, workspace, workspace_bytes, st);
+    return vg_internal_ring_conv(0, x, packed, bias, y, B, Cin, H, W, Cout, planes, workspace, workspace_bytes,
+                                 fuse ? fuse->in_scale : nullptr, fuse ? fuse->in_shift : nullptr, fuse ? fuse->in_act : 0,
+                                 fuse ? fuse->stats : nullptr, fuse ? fuse->stats_floats : 0, st);
+  if (!fuse_empty(fuse)) return VG_ERR_BAD_ARG;        // vg_conv5x5_bf16split_fusable says which layers take it
   const bf16x8* w = (const bf16x8*)packed;
   const int k = fwd_ksplit(B, Cin, H, W, Cout, stride);
   if (k > 1 && (!workspace || workspace_bytes < vg_conv5x5_fwd_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride)))
@@ -571,11 +591,14 @@ extern "C" size_t vg_convT5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int 
 
 extern "C" int vg_convT5x5_fwd_bf16split(const float* x, const void* packed, const float* bias, float* y, int B, int Cin,
                                       int H, int W, int Cout, int stride, int planes, void* workspace,
-                                      size_t workspace_bytes, void* stream) {
+                                      size_t workspace_bytes, const vg_conv_fusion* fuse, void* stream) {
   if (!x_args_ok(x, packed, y, B, Cin, H, W, Cout, stride, planes)) return VG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (tr_on_ring(Cout, stride))
-    return vg_internal_ring_conv(1, x, packed, bias, y, B, Cin, H, W, Cout, planes, workspace, workspace_bytes, st);
+    return vg_internal_ring_conv(1, x, packed, bias, y, B, Cin, H, W, Cout, planes, workspace, workspace_bytes,
+                                 fuse ? fuse->in_scale : nullptr, fuse ? fuse->in_shift : nullptr, fuse ? fuse->in_act : 0,
+                                 fuse ? fuse->stats : nullptr, fuse ? fuse->stats_floats : 0, st);
+  if (!fuse_empty(fuse)) return VG_ERR_BAD_ARG;
   const bf16x8* w = (const bf16x8*)packed;
   if (planes == 2) {
     if (stride == 2) return dispatch_x<X_TR, 2, 2>(x, w, bias, y, B, Cin, H, W, Cout, XSplit{1, nullptr}, st);

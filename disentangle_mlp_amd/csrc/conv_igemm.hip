@@ -72,6 +72,8 @@ struct Args {
   int B, Cin, XH, XW, Cout, YH, YW;
   int CinP, CoutP;   // PK: padded extents of the packed filter
   int ntiles_n, tiles_w, tiles_hw, blocks_per_cls;
+  float* stats;      // optional [slot][Cout][2]: per-channel sum y, sum y^2 of each (pixel tile, wavefront row) --
+                     // the statistics of the BatchNorm that follows (forward convolution only; vg_conv_fusion.stats)
 };
 
 // Padded extents of the packed filter: whole K chunks (<= 8 channels) and whole cout tiles.
@@ -322,6 +324,39 @@ __device__ __forceinline__ void igemm_body(const Args& A, float* smem, int bid) 
   }
   // ---- epilogue: + bias, NCHW store
   const int YH = A.YH, YW = A.YW;
+  if (MODE == MODE_FWD && A.stats) {
+    bool pokf[FP];
+#pragma unroll
+    for (int f = 0; f < FP; ++f) {
+      const int m = (wp * FP + f) * 32 + l32;
+      const int nb = m / (TH * TW), r = m % (TH * TW);
+      pokf[f] = (b0 + nb) < A.B && (th0 + r / TW) < YH && (tw0 + r % TW) < YW;
+    }
+    float* sb = A.stats + (size_t)(pt * C::WP + wp) * Cout * 2;
+#pragma unroll
+    for (int g = 0; g < FC; ++g)
+#pragma unroll
+      for (int r16 = 0; r16 < 16; ++r16) {
+        const int co = n0 + (wc * FC + g) * 32 + acc_row(r16, lane);
+        const float bvs = A.bias ? A.bias[min(co, Cout - 1)] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int f = 0; f < FP; ++f) {
+          const float v = pokf[f] ? acc[g][f][r16] + bvs : 0.f;
+          s1 += v;
+          s2 = fmaf(v, v, s2);
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {       // the 32 lanes of a half hold the 32 pixels of this cout row
+          s1 += __shfl_xor(s1, o, 64);
+          s2 += __shfl_xor(s2, o, 64);
+        }
+        if (l32 == 0 && co < Cout) {
+          sb[2 * co] = s1;
+          sb[2 * co + 1] = s2;
+        }
+      }
+  }
 #pragma unroll
   for (int f = 0; f < FP; ++f) {
     const int m = (wp * FP + f) * 32 + l32;
@@ -366,11 +401,19 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv5x5_igemm_kernel(Args A) {
   }
 }
 
+// statistics request of a launch: `need` != NULL: only report the floats the chosen tile variant would write
+struct IgStats {
+  float* ptr;
+  size_t cap;
+  size_t* need;
+};
+
 template <class C>
 int launch(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int XH, int XW,
-           int Cout, hipStream_t st) {
+           int Cout, hipStream_t st, const IgStats* sx = nullptr) {
   Args A;
   A.x = x; A.w = w; A.bias = bias; A.y = y;
+  A.stats = nullptr;
   A.B = B; A.Cin = Cin; A.XH = XH; A.XW = XW; A.Cout = Cout;
   A.CinP = packed_cin(Cin); A.CoutP = packed_cout(Cout);
   int tsh, tsw;  // tile-space extent
@@ -389,6 +432,17 @@ int launch(const float* x, const float* w, const float* bias, float* y, int B, i
   A.blocks_per_cls = (int)per_cls;
   const long grid = per_cls * C::NCLS;
   if (grid <= 0 || grid > 0x7fffffffL) return VG_ERR_BAD_ARG;
+  if (sx) {
+    const size_t floats = (C::MODE == MODE_FWD) ? (size_t)(per_cls / A.ntiles_n) * C::WP * Cout * 2 : 0;
+    if (sx->need) {
+      *sx->need = floats;
+      return 0;
+    }
+    if (sx->ptr) {
+      if (!floats || sx->cap < floats) return VG_ERR_BAD_ARG;
+      A.stats = sx->ptr;
+    }
+  }
   hipLaunchKernelGGL(conv5x5_igemm_kernel<C>, dim3((unsigned)grid), dim3(C::NT), 0, st, A);
   VG_CHECK_LAUNCH();
   return 0;
@@ -445,16 +499,16 @@ constexpr int g_tile_override[2] = {-1, -1};
 
 template <int MODE, int S, int WIDTH, bool PK>
 int launch_var(int var, const float* x, const float* w, const float* bias, float* y, int B, int Cin, int XH,
-               int XW, int Cout, hipStream_t st) {
+               int XW, int Cout, hipStream_t st, const IgStats* sx = nullptr) {
   switch (var) {
-    case 0: return launch<typename Pick<MODE, S, WIDTH, 0, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    case 1: return launch<typename Pick<MODE, S, WIDTH, 1, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    case 2: return launch<typename Pick<MODE, S, WIDTH, 2, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    case 3: return launch<typename Pick<MODE, S, WIDTH, 3, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    case 4: return launch<typename Pick<MODE, S, WIDTH, 4, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    case 5: return launch<typename Pick<MODE, S, WIDTH, 5, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    case 6: return launch<typename Pick<MODE, S, WIDTH, 6, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
-    default: return launch<typename Pick<MODE, S, WIDTH, 7, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st);
+    case 0: return launch<typename Pick<MODE, S, WIDTH, 0, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st, sx);
+    case 1: return launch<typename Pick<MODE, S, WIDTH, 1, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st, sx);
+    case 2: return launch<typename Pick<MODE, S, WIDTH, 2, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st, sx);
+    case 3: return launch<typename Pick<MODE, S, WIDTH, 3, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st, sx);
+    case 4: return launch<typename Pick<MODE, S, WIDTH, 4, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st, sx);
+    case 5: return launch<typename Pick<MODE, S, WIDTH, 5, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st, sx);
+    case 6: return launch<typename Pick<MODE, S, WIDTH, 6, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st, sx);
+    default: return launch<typename Pick<MODE, S, WIDTH, 7, PK>::type>(x, w, bias, y, B, Cin, XH, XW, Cout, st, sx);
   }
 }
 
@@ -462,7 +516,7 @@ int launch_var(int var, const float* x, const float* w, const float* bias, float
 // when the big ones would leave CUs idle (256 CUs x 2 resident workgroups).
 template <int MODE, int S, bool PK>
 int dispatch(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int XH, int XW,
-             int Cout, hipStream_t st) {
+             int Cout, hipStream_t st, const IgStats* sx = nullptr) {
   const int tsw = (MODE == MODE_FWD) ? (XW - 1) / S + 1 : XW;
   const int tsh = (MODE == MODE_FWD) ? (XH - 1) / S + 1 : XH;
   const int width = tsw >= 32 ? 32 : (tsw >= 16 ? 16 : 8);
@@ -490,9 +544,9 @@ int dispatch(const float* x, const float* w, const float* bias, float* y, int B,
   }
   const int ov = g_tile_override[MODE];
   const int use = (ov >= 0 && ov < NVAR) ? ov : var;
-  if (width == 32) return launch_var<MODE, S, 32, PK>(use, x, w, bias, y, B, Cin, XH, XW, Cout, st);
-  if (width == 16) return launch_var<MODE, S, 16, PK>(use, x, w, bias, y, B, Cin, XH, XW, Cout, st);
-  return launch_var<MODE, S, 8, PK>(use, x, w, bias, y, B, Cin, XH, XW, Cout, st);
+  if (width == 32) return launch_var<MODE, S, 32, PK>(use, x, w, bias, y, B, Cin, XH, XW, Cout, st, sx);
+  if (width == 16) return launch_var<MODE, S, 16, PK>(use, x, w, bias, y, B, Cin, XH, XW, Cout, st, sx);
+  return launch_var<MODE, S, 8, PK>(use, x, w, bias, y, B, Cin, XH, XW, Cout, st, sx);
 }
 
 // ---- filter pre-pack: [class][ci][tap][CoutP], zero padded to CinP x CoutP.  One workgroup
@@ -574,6 +628,26 @@ extern "C" int vg_conv5x5_fwd_packed(const float* x, const float* packed, const 
   hipStream_t st = (hipStream_t)stream;
   if (stride == 2) return dispatch<MODE_FWD, 2, true>(x, packed, bias, y, B, Cin, H, W, Cout, st);
   return dispatch<MODE_FWD, 1, true>(x, packed, bias, y, B, Cin, H, W, Cout, st);
+}
+
+extern "C" size_t vg_conv5x5_fwd_packed_stats_floats(int B, int Cin, int H, int W, int Cout, int stride) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return 0;
+  size_t need = 0;
+  const IgStats sx = {nullptr, 0, &need};
+  const int rc = (stride == 2) ? dispatch<MODE_FWD, 2, true>(nullptr, nullptr, nullptr, nullptr, B, Cin, H, W, Cout, nullptr, &sx)
+                               : dispatch<MODE_FWD, 1, true>(nullptr, nullptr, nullptr, nullptr, B, Cin, H, W, Cout, nullptr, &sx);
+  return rc == 0 ? need : 0;
+}
+
+extern "C" int vg_conv5x5_fwd_packed_stats(const float* x, const float* packed, const float* bias, float* y, int B,
+                                           int Cin, int H, int W, int Cout, int stride, float* stats,
+                                           size_t stats_floats, void* stream) {
+  if (!conv_args_ok(x, packed, y, B, Cin, H, W, Cout, stride) || ((uintptr_t)packed & 15) != 0 || !stats)
+    return VG_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const IgStats sx = {stats, stats_floats, nullptr};
+  if (stride == 2) return dispatch<MODE_FWD, 2, true>(x, packed, bias, y, B, Cin, H, W, Cout, st, &sx);
+  return dispatch<MODE_FWD, 1, true>(x, packed, bias, y, B, Cin, H, W, Cout, st, &sx);
 }
 
 extern "C" int vg_convT5x5_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin,

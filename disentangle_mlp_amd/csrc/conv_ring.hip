@@ -63,8 +63,10 @@ struct RCfg {
   static constexpr int LDSU = RINGU + PATCHU + 1;                      // + one dummy unit for masked staging writes
   static constexpr int DMA_TOTAL = SLOTU / 64;                         // 1 KiB DMA instructions per step
   static constexpr int NDMA = (DMA_TOTAL + 7) / 8;                     // per wavefront (every wavefront the same count)
-  static constexpr int NUNIT = (MODE == R_FWD) ? NB * PH * PW : 2 * NB * PH * PW;   // staged units per staging event
-  static constexpr int NQ = (NUNIT + RNT - 1) / RNT;
+  // staged units per staging event: NB * PH * PW pixels of 8 channels (FWD) or of 2 x 8 channels (TR: unit q of a
+  // thread belongs to k-block q & 1, so that a unit's channels are wave-uniform)
+  static constexpr int NPIX = NB * PH * PW;
+  static constexpr int NQ = ((MODE == R_FWD) ? 1 : 2) * ((NPIX + RNT - 1) / RNT);
   static constexpr int NL = NQ * 8;                                    // plain global loads per staging event
   static constexpr int NCLS = (MODE == R_FWD) ? 1 : 4;
   static_assert(TM == 32 * WP * FP, "pixel tile");
@@ -82,6 +84,14 @@ struct RArgs {
   int ntiles_n, tiles_w, tiles_hw, blocks_per_cls;
   int cps;             // channel chunks per K split
   size_t ysplit;       // elements per partial output slab (ksplit > 1: y points at the slabs)
+  // fused BatchNorm (vg_conv_fusion): the INPUT is read as act(x * in_scale[c] + in_shift[c]) -- the train-mode
+  // BatchNorm + activation of the producing layer applied while the patch is staged (zero padding applies to the
+  // activated tensor) -- and per-channel sums of the OUTPUT (sum y, sum y^2 over this workgroup's pixels, one slot
+  // per wavefront row) are left for the next BatchNorm's statistics.  NULL pointers: plain convolution.
+  const float* in_scale;
+  const float* in_shift;
+  int in_act;
+  float* stats;        // [slot][Cout][2]
 };
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
@@ -98,6 +108,8 @@ __host__ __device__ constexpr int tr_taps_before(int R, int SS) {
     }
   return n;
 }
+
+__device__ const float k_unit_scale = 1.f, k_zero_shift = 0.f;      // the "no fusion" input coefficients
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -161,14 +173,15 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
   auto unit_of = [&](int q) -> Unit {
     int t0 = tid;
     asm volatile("" : "+v"(t0));                       // opaque: keeps the map from being hoisted out of the loop
-    const int e = t0 + q * RNT;
+    const int kbs = (MODE == R_FWD) ? 0 : (q & 1);
+    const int e = t0 + ((MODE == R_FWD) ? q : (q >> 1)) * RNT;
     const int col = e % PW;
     int t = e / PW;
     const int r = t % PH;
     t /= PH;
-    const int nb = t % NB, kbs = (MODE == R_FWD) ? 0 : min(t / NB, 1);
+    const int nb = t % NB;
     const int ih = ih0 + r, iw = iw0 + col;
-    const bool in = e < C::NUNIT;
+    const bool in = e < C::NPIX;
     Unit u;
     u.ok = in && ih >= 0 && ih < XH && iw >= 0 && iw < XW && (b0 + nb) < A.B;
     const int nbc = min(nb, A.B - 1 - b0), ihc = min(max(ih, 0), XH - 1), iwc = min(max(iw, 0), XW - 1);
@@ -178,10 +191,16 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
   };
 
   float preg[NQ][8];
+  int staged_c0 = 0;      // first channel of the units in preg (wave-uniform)
+  const int aff_mask = A.in_scale ? -1 : 0;
+  const float* aff_scale = A.in_scale ? A.in_scale : &k_unit_scale;
+  const float* aff_shift = A.in_scale ? A.in_shift : &k_zero_shift;
+  const float aff_slope = !A.in_scale || A.in_act == VG_ACT_NONE ? 1.f : (A.in_act == VG_ACT_RELU ? 0.f : 0.2f);
   // c0 = first channel of the 8 (FWD) / 16 (TR) channels to stage; clamped so that the address stays in the tensor
   // (past-the-end events happen at the last chunk and are never consumed)
   auto stage_load = [&](int c0) {
     c0 = min(c0, Cin - ((MODE == R_FWD) ? 8 : 16));
+    staged_c0 = c0;
     unsigned ofs[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) ofs[q] = unit_of(q).ofs;
@@ -195,9 +214,15 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
   auto split_unit = [&](int q, int bufu) {          // fp32 -> planes of staged unit q, written to buffer `bufu`
     const Unit u = unit_of(q);
     bf16x8 pl[NP];
+    // BatchNorm + activation of the producing layer, on load -- branch-free (a branch here keeps hipcc from unrolling
+    // the K steps, and the fragment registers then go to scratch): without a fusion the coefficients are 1 / 0 /
+    // slope 1 read from element 0 of constant arrays.  Scalar loads: a unit's channels are wave-uniform.
+    const int cb = aff_mask & (staged_c0 + ((MODE == R_FWD) ? 0 : (q & 1) * 8));
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float v = u.ok ? preg[q][j] : 0.f;
+      float v = fmaf(preg[q][j], aff_scale[cb + (aff_mask & j)], aff_shift[cb + (aff_mask & j)]);
+      v = fmaxf(v, 0.f) + aff_slope * fminf(v, 0.f);  // slope 1: identity, 0: ReLU, 0.2: LeakyReLU
+      v = u.ok ? v : 0.f;                             // zero padding pads the ACTIVATED tensor
 #pragma unroll
       for (int p = 0; p < NP; ++p) {                // hi, (mid,) lo: each plane takes the leading 8 bits of what is left
         const __bf16 h = (__bf16)v;
@@ -403,8 +428,46 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
   }
   wait_vmcnt<0>();     // nothing of the ring is in flight when the workgroup ends
 
-  // ---- epilogue: + bias, NCHW store (as conv_igemm.hip)
   const int YH = A.YH, YW = A.YW;
+  // ---- optional: per-channel sums of the output for the next BatchNorm (ksplit == 1 only: the host says so)
+  if (A.stats) {
+    bool pokf[FP];
+#pragma unroll
+    for (int f = 0; f < FP; ++f) {
+      const int m = (wp * FP + f) * 32 + l32;
+      const int nb = m / (TH * TW), r = m % (TH * TW);
+      const int th = th0 + r / TW, tw = tw0 + r % TW;
+      const int oh = (MODE == R_FWD) ? th : S * th + R, ow = (MODE == R_FWD) ? tw : S * tw + SS;
+      pokf[f] = (b0 + nb) < A.B && oh < YH && ow < YW;
+    }
+    const int cls = (MODE == R_FWD) ? 0 : 2 * R + SS;
+    const int slot = (cls * (A.blocks_per_cls / A.ntiles_n) + pt) * C::WP + wp;
+    float* sb = A.stats + (size_t)slot * Cout * 2;
+#pragma unroll
+    for (int g = 0; g < FC; ++g)
+#pragma unroll
+      for (int r16 = 0; r16 < 16; ++r16) {
+        const int co = n0 + (wc * FC + g) * 32 + acc_row(r16, lane);
+        const float bvs = A.bias ? A.bias[min(co, Cout - 1)] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int f = 0; f < FP; ++f) {
+          const float v = pokf[f] ? acc[g][f][r16] + bvs : 0.f;
+          s1 += v;
+          s2 = fmaf(v, v, s2);
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {       // the 32 lanes of a half hold the 32 pixels of this cout row
+          s1 += __shfl_xor(s1, o, 64);
+          s2 += __shfl_xor(s2, o, 64);
+        }
+        if (l32 == 0 && co < Cout) {
+          sb[2 * co] = s1;
+          sb[2 * co + 1] = s2;
+        }
+      }
+  }
+  // ---- epilogue: + bias, NCHW store (as conv_igemm.hip)
 #pragma unroll
   for (int f = 0; f < FP; ++f) {
     const int m = (wp * FP + f) * 32 + l32;
@@ -455,11 +518,20 @@ __global__ __launch_bounds__(RNT, 2) void conv5x5_ring_kernel(RArgs A) {
   }
 }
 
+struct RFuse {
+  const float* in_scale;
+  const float* in_shift;
+  int in_act;
+  float* stats;
+};
+
 template <class C>
 int launch_ring(const float* x, const bf16x8* w, const float* bias, float* y, int B, int Cin, int XH, int XW, int Cout,
-                int ksplit, float* slabs, hipStream_t st) {
+                int ksplit, float* slabs, RFuse fu, hipStream_t st) {
   RArgs A;
   A.x = x; A.w = w; A.bias = bias; A.y = y;
+  A.in_scale = fu.in_scale; A.in_shift = fu.in_shift; A.in_act = fu.in_act;
+  A.stats = (ksplit == 1) ? fu.stats : nullptr;
   A.B = B; A.Cin = Cin; A.XH = XH; A.XW = XW; A.Cout = Cout; A.CoutP = (Cout + 127) & ~127;
   int tsh, tsw;
   if (C::MODE == R_FWD) {
@@ -491,18 +563,18 @@ int launch_ring(const float* x, const bf16x8* w, const float* bias, float* y, in
 // pixel-tile geometry by the width of the tiled image (forward: output, transposed: input)
 template <int MODE, int WC, int FC, int FP, int NP>
 int ring_geom(const float* x, const bf16x8* w, const float* bias, float* y, int B, int Cin, int XH, int XW, int Cout,
-              int ksplit, float* slabs, hipStream_t st) {
+              int ksplit, float* slabs, RFuse fu, hipStream_t st) {
   const int tsw = (MODE == R_FWD) ? (XW - 1) / 2 + 1 : XW;
   constexpr int TM = 32 * (8 / WC) * FP;
   static_assert(TM == 128 || TM == 256, "pixel tile");
   if constexpr (TM == 128) {
-    if (tsw > 8) return launch_ring<RCfg<MODE, 1, 8, 16, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, st);
+    if (tsw > 8) return launch_ring<RCfg<MODE, 1, 8, 16, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
     // transposed, 8-wide images, 256 cout: ring + the two 2 x 10 x 10 patches (24 units per row) exceed the LDS;
     // the plan sends those layers to the 128-cout tiles
     if constexpr (MODE == R_TR && WC * FC * 32 == 256) return VG_ERR_BAD_ARG;
-    else return launch_ring<RCfg<MODE, 2, 8, 8, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, st);
+    else return launch_ring<RCfg<MODE, 2, 8, 8, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
   } else {   // 256 pixels: whole 16 x 16 tiles only (the plan never picks it for narrower images)
-    return launch_ring<RCfg<MODE, 1, 16, 16, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, st);
+    return launch_ring<RCfg<MODE, 1, 16, 16, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
   }
 }
 
@@ -515,13 +587,13 @@ VG_KNOB(int, g_ring_variant, -1);   // tuning build only: forced tile variant
 // 128 cout x 256 px (2 x 4 wavefronts of 64 x 64).
 template <int MODE, int NP>
 static int ring_dispatch(int variant, const float* x, const bf16x8* w, const float* bias, float* y, int B, int Cin, int XH,
-                         int XW, int Cout, int ksplit, float* slabs, hipStream_t st) {
+                         int XW, int Cout, int ksplit, float* slabs, RFuse fu, hipStream_t st) {
   switch (variant) {
-    case 0: return ring_geom<MODE, 4, 2, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, st);
-    case 1: return ring_geom<MODE, 2, 2, 1, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, st);
-    case 2: return ring_geom<MODE, 4, 1, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, st);
+    case 0: return ring_geom<MODE, 4, 2, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
+    case 1: return ring_geom<MODE, 2, 2, 1, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
+    case 2: return ring_geom<MODE, 4, 1, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
     default:
-      if constexpr (MODE == R_TR) return ring_geom<MODE, 2, 2, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, st);
+      if constexpr (MODE == R_TR) return ring_geom<MODE, 2, 2, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
       return VG_ERR_BAD_ARG;
   }
 }
@@ -566,19 +638,36 @@ size_t vg_internal_ring_workspace_bytes(int mode, int B, int Cin, int H, int W, 
   return (size_t)p.ksplit * B * Cout * yh * yw * sizeof(float);
 }
 
+// Floats of the output-statistics buffer ([slot][Cout][2]; one slot per (class, pixel tile, wavefront row)); 0 when
+// the layer runs K-split (its partial outputs never meet in one workgroup: statistics come from a pass over y).
+size_t vg_internal_ring_stats_floats(int mode, int B, int Cin, int H, int W, int Cout) {
+  const RingPlan p = ring_plan(mode, B, Cin, H, W, Cout);
+  if (p.ksplit > 1) return 0;
+  const int tsw = (mode == R_FWD) ? (W - 1) / 2 + 1 : W, tsh = (mode == R_FWD) ? (H - 1) / 2 + 1 : H;
+  long tiles;
+  if (p.variant == 3) tiles = (long)B * cdiv(tsh, 16) * cdiv(tsw, 16);
+  else tiles = (tsw > 8) ? (long)B * cdiv(tsh, 8) * cdiv(tsw, 16) : (long)cdiv(B, 2) * cdiv(tsh, 8) * cdiv(tsw, 8);
+  const int wp = (p.variant == 0 || p.variant == 2) ? 2 : 4;
+  return (size_t)tiles * wp * ((mode == R_TR) ? 4 : 1) * Cout * 2;
+}
+
 int vg_internal_ring_conv(int mode, const float* x, const void* packed, const float* bias, float* y, int B, int Cin, int H,
-                          int W, int Cout, int planes, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                          int W, int Cout, int planes, void* workspace, size_t workspace_bytes, const float* in_scale,
+                          const float* in_shift, int in_act, float* stats, size_t stats_floats, hipStream_t st) {
   const RingPlan p = ring_plan(mode, B, Cin, H, W, Cout);
   if (p.ksplit > 1 && (!workspace || workspace_bytes < vg_internal_ring_workspace_bytes(mode, B, Cin, H, W, Cout)))
     return VG_ERR_WORKSPACE;
+  if ((in_scale == nullptr) != (in_shift == nullptr) || in_act < VG_ACT_NONE || in_act > VG_ACT_LRELU) return VG_ERR_BAD_ARG;
+  if (stats && (p.ksplit > 1 || stats_floats < vg_internal_ring_stats_floats(mode, B, Cin, H, W, Cout))) return VG_ERR_BAD_ARG;
+  const RFuse fu = {in_scale, in_shift, in_act, stats};
   const bf16x8* w = (const bf16x8*)packed;
   float* slabs = (float*)workspace;
   if (mode == R_FWD) {
-    if (planes == 3) return ring_dispatch<R_FWD, 3>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, st);
-    return ring_dispatch<R_FWD, 2>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, st);
+    if (planes == 3) return ring_dispatch<R_FWD, 3>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, fu, st);
+    return ring_dispatch<R_FWD, 2>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, fu, st);
   }
-  if (planes == 3) return ring_dispatch<R_TR, 3>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, st);
-  return ring_dispatch<R_TR, 2>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, st);
+  if (planes == 3) return ring_dispatch<R_TR, 3>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, fu, st);
+  return ring_dispatch<R_TR, 2>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, fu, st);
 }
 
 #ifdef VG_TUNING

@@ -33,6 +33,10 @@ constexpr int WTW = 8, WCIT = 5;
 struct WXArgs {
   const float* x;      // NCHW fp32 (the patch is split while it is staged)
   int B;
+  // fused BatchNorm: x is read as act(x * in_scale[ci] + in_shift[ci]) (vg_conv_fusion semantics); NULL: as it is
+  const float* in_scale;
+  const float* in_shift;
+  float in_slope;      // activation as max(v, 0) + slope * min(v, 0): 1 none, 0 ReLU, 0.2 LeakyReLU
   const bf16x8* gp;
   float* ws;
   int Cin, H, W, Cout, CoP, OH, OW;
@@ -59,9 +63,12 @@ __device__ __forceinline__ void split_planes(float* v, bf16x8* out) {
 }
 
 // ---- gy[B][Co][P] -> Gp[bg][p][plane][kb][CoP] x 8 images; 32 pixels x 32 channels per workgroup
+// optional g_scale / g_shift / g_slope: the operand is read as act(gy * scale[co] + shift[co]) (a fused BatchNorm: the
+// weight gradient of a TRANSPOSED convolution takes the layer's input here)
 template <int NP>
 __global__ __launch_bounds__(256) void relayout_gy_kernel(const float* __restrict__ gy, bf16x8* __restrict__ gp,
-                                                         int B, int Co, int CoP, int P) {
+                                                         int B, int Co, int CoP, int P, const float* __restrict__ g_scale,
+                                                         const float* __restrict__ g_shift, float g_slope) {
   __shared__ float tile[8][32][33];
   const int tid = threadIdx.x;
   const int p0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
@@ -75,7 +82,13 @@ __global__ __launch_bounds__(256) void relayout_gy_kernel(const float* __restric
       for (int rr = 0; rr < 4; ++rr) {
         const int co = co0 + r + 8 * rr;
         float v = 0.f;
-        if (b < B && co < Co && p0 + pl < P) v = gy[((size_t)b * Co + co) * P + p0 + pl];
+        if (b < B && co < Co && p0 + pl < P) {
+          v = gy[((size_t)b * Co + co) * P + p0 + pl];
+          if (g_scale) {
+            v = fmaf(v, g_scale[co], g_shift[co]);
+            v = fmaxf(v, 0.f) + g_slope * fminf(v, 0.f);
+          }
+        }
         tile[j][r + 8 * rr][pl] = v;
       }
     }
@@ -173,7 +186,7 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
     oh = sp / A.tiles_w;
     ow0 = (sp % A.tiles_w) * WTW;
   };
-  float preg[NQ][8];
+  float preg[NQ][8], psc[NQ], psh[NQ];
   unsigned pvalid = 0;
   const size_t chw = (size_t)Cin * HW;
   auto load_patch = [&](int chunk) {
@@ -188,7 +201,10 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
       const int ci = (d >> 9) & 7, kbs = (d >> 12) & 1;
       const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
       pvalid |= ok ? (1u << q) : 0u;
-      const unsigned off = (unsigned)(min(ci0 + ci, Cin - 1) * HW + min(max(ih, 0), H - 1) * W + min(max(iw, 0), W - 1));
+      const int cc = min(ci0 + ci, Cin - 1);
+      const unsigned off = (unsigned)(cc * HW + min(max(ih, 0), H - 1) * W + min(max(iw, 0), W - 1));
+      psc[q] = A.in_scale ? A.in_scale[cc] : 1.f;
+      psh[q] = A.in_scale ? A.in_shift[cc] : 0.f;
       const int b0 = bg * 16 + kbs * 8;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -206,7 +222,11 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
       const bool live = state == 1 && ((pvalid >> q) & 1u);
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (live && (bgrp * 16 + kbs * 8 + j) < A.B) ? preg[q][j] : 0.f;
+      for (int j = 0; j < 8; ++j) {
+        float t = fmaf(preg[q][j], psc[q], psh[q]);                    // the producing layer's BatchNorm ...
+        t = fmaxf(t, 0.f) + A.in_slope * fminf(t, 0.f);                // ... and activation, on load
+        v[j] = (live && (bgrp * 16 + kbs * 8 + j) < A.B) ? t : 0.f;    // padding pads the activated tensor
+      }
       bf16x8 pl[NP];
       split_planes<NP>(v, pl);
       const int dst = buf * BUFU + kbs * KBU + ((d >> 9) & 7) * CIU + (d & 15) * ROWU + ((d >> 4) & 31);
@@ -360,8 +380,14 @@ extern "C" size_t vg_conv5x5_wgrad_bf16split_workspace_bytes(int B, int Cin, int
 
 extern "C" int vg_conv5x5_wgrad_bf16split(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W,
                                        int Cout, int stride, int planes, void* workspace, size_t workspace_bytes,
+                                       const float* in_scale, const float* in_shift, int in_act, int affine_on_gy,
                                        void* stream) {
   if (!x || !gy || !dw || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return VG_ERR_BAD_ARG;
+  if ((in_scale == nullptr) != (in_shift == nullptr) || in_act < VG_ACT_NONE || in_act > VG_ACT_LRELU) return VG_ERR_BAD_ARG;
+  const float slope = (!in_scale || in_act == VG_ACT_NONE) ? 1.f : (in_act == VG_ACT_RELU ? 0.f : 0.2f);
+  const float* gsc = affine_on_gy ? in_scale : nullptr;      // coefficients per channel of gy (Cout of them) ...
+  const float* gsh = affine_on_gy ? in_shift : nullptr;
+  if (affine_on_gy) in_scale = in_shift = nullptr;           // ... or per channel of x (Cin)
   if ((stride != 1 && stride != 2) || (planes != 2 && planes != 3)) return VG_ERR_BAD_ARG;
   XPlan p;
   if (!make_xplan(B, Cin, H, W, Cout, stride, planes, p)) return VG_ERR_BAD_ARG;
@@ -373,11 +399,13 @@ extern "C" int vg_conv5x5_wgrad_bf16split(const float* x, const float* gy, float
   const int P = p.OH * p.OW;
   if ((size_t)Cin * H * W * 4 > 0xffffffffUL || p.BG * 2 > 65535 || p.CoP / 32 > 65535) return VG_ERR_BAD_ARG;
   const dim3 gg(cdiv(P, 32), p.CoP / 32, p.BG * 2);
-  if (planes == 2) hipLaunchKernelGGL(relayout_gy_kernel<2>, gg, dim3(256), 0, st, gy, gp, B, Cout, p.CoP, P);
-  else hipLaunchKernelGGL(relayout_gy_kernel<3>, gg, dim3(256), 0, st, gy, gp, B, Cout, p.CoP, P);
+  if (planes == 2) hipLaunchKernelGGL(relayout_gy_kernel<2>, gg, dim3(256), 0, st, gy, gp, B, Cout, p.CoP, P, gsc, gsh, slope);
+  else hipLaunchKernelGGL(relayout_gy_kernel<3>, gg, dim3(256), 0, st, gy, gp, B, Cout, p.CoP, P, gsc, gsh, slope);
   VG_CHECK_LAUNCH();
   WXArgs A;
   A.x = x; A.B = B; A.gp = gp; A.ws = slabs;
+  A.in_scale = in_scale; A.in_shift = in_shift;
+  A.in_slope = in_scale ? slope : 1.f;
   A.Cin = Cin; A.H = H; A.W = W; A.Cout = Cout; A.CoP = p.CoP; A.OH = p.OH; A.OW = p.OW;
   A.mtiles = p.mtiles; A.ntiles = p.ntiles; A.splits = p.splits; A.tiles_w = p.tiles_w; A.tiles_hw = p.tiles_hw;
   A.chunks = p.chunks; A.chunks_per_split = p.cps;

@@ -70,11 +70,18 @@ class ConvT5x5Fn(Function):
 
 class BNActFn(Function):
     """Train-mode BatchNorm1d/2d + {none, ReLU, LeakyReLU(0.2)} -- model.py:451-452 etc.
-    running_mean / running_var are updated in place by the kernel."""
+    running_mean / running_var are updated in place by the kernel.  ``stats``: the statistics slots the producing
+    convolution left (ops.conv5x5_fwd(..., want_stats=True)); then the statistics pass over x is skipped."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act):
-        y, mean, invstd = ops.bn_act_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, act)
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act, stats=None):
+        if stats is not None and (x.numel() // (x.shape[0] * x.shape[1])) % 4 == 0:
+            count = x.numel() // x.shape[1]
+            mean, invstd, scale, shift = ops.bn_finalize_stats(stats, count, gamma, beta, running_mean, running_var,
+                                                               eps, momentum)
+            y = ops.affine_act(x, scale, shift, act)
+        else:
+            y, mean, invstd = ops.bn_act_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, act)
         ctx.act = act
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
         return y
@@ -85,7 +92,88 @@ class BNActFn(Function):
         x, gamma, beta, mean, invstd = ctx.saved_tensors
         need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         gx, dg, db = ops.bn_act_bwd(gy.contiguous(), x, gamma, beta, mean, invstd, ctx.act, need_p)
-        return gx, dg, db, None, None, None, None, None
+        return gx, dg, db, None, None, None, None, None, None
+
+
+class ConvStatsFn(Function):
+    """conv / transposed conv that also returns the statistics slots of its output (a non-differentiable side
+    product of the kernel's epilogue; an empty tensor when this layer's kernel cannot emit them)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, transposed, bias_grad):
+        ctx.stride, ctx.transposed, ctx.bias_grad = stride, transposed, bias_grad
+        ctx.save_for_backward(x, w)
+        conv = ops.convT5x5_fwd if transposed else ops.conv5x5_fwd
+        y, stats = conv(x, w, bias, stride, want_stats=True)
+        stats = stats if stats is not None else x.new_empty(0)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy, _):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        s, tr = ctx.stride, ctx.transposed
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            if not tr and (x.shape[2] % s or x.shape[3] % s):
+                raise RuntimeError("conv5x5 data gradient needs input sizes divisible by the stride")
+            gx = ops.conv5x5_fwd(gy, w, None, s) if tr else ops.convT5x5_fwd(gy, w, None, s)
+        if ctx.needs_input_grad[1]:
+            gw = ops.conv5x5_wgrad(gy, x, s) if tr else ops.conv5x5_wgrad(x, gy, s)
+        if ctx.needs_input_grad[2]:
+            gb = torch.zeros(w.shape[1 if tr else 0], dtype=gy.dtype, device=gy.device) \
+                if ctx.bias_grad == BIAS_GRAD_ZERO else ops.channel_sum(gy)
+        return gx, gw, gb, None, None, None
+
+
+class BNConvFn(Function):
+    """[train-mode BatchNorm2d + activation] -> [5x5 conv / transposed conv] with the normalised, activated tensor
+    NEVER materialised (model.py:451-456, 390-398, 496-505): the BatchNorm's statistics come from the
+    slots the producing convolution left (``stats_in``, or one pass over x when there are none), its scale / shift
+    and activation are applied by the consuming convolution while it stages its input -- forward, and again by the
+    weight gradient in backward.  Backward: data gradient of the convolution (w.r.t. the activated tensor), then the
+    ordinary BatchNorm backward against the saved raw x (vg_bn_act_bwd: mask recomputed from x).
+    Returns (y, statistics slots of y -- empty when the kernel cannot emit them)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w, bias, running_mean, running_var, eps, momentum, act, stride, transposed,
+                bias_grad, stats_in):
+        count = x.numel() // x.shape[1]
+        if stats_in is not None and stats_in.numel():
+            mean, invstd, scale, shift = ops.bn_finalize_stats(stats_in, count, gamma, beta, running_mean, running_var,
+                                                               eps, momentum)
+        else:
+            mean, invstd, scale, shift = ops.bn_stats(x, gamma, beta, running_mean, running_var, eps, momentum)
+        conv = ops.convT5x5_fwd if transposed else ops.conv5x5_fwd
+        y, stats = conv(x, w, bias, stride, in_affine=(scale, shift, act), want_stats=True)
+        stats = stats if stats is not None else x.new_empty(0)
+        ctx.act, ctx.stride, ctx.transposed, ctx.bias_grad = act, stride, transposed, bias_grad
+        ctx.save_for_backward(x, gamma, beta, mean, invstd, scale, shift, w)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy, _):
+        x, gamma, beta, mean, invstd, scale, shift, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        s, tr, act = ctx.stride, ctx.transposed, ctx.act
+        need_bn = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        gx = dg = db = gw = gb = None
+        if need_bn:
+            ga = ops.conv5x5_fwd(gy, w, None, s) if tr else ops.convT5x5_fwd(gy, w, None, s)    # grad w.r.t. act(BN(x))
+            gx, dg, db = ops.bn_act_bwd(ga, x, gamma, beta, mean, invstd, act,
+                                        ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        if ctx.needs_input_grad[3]:
+            aff = (scale, shift, act)
+            gw = ops.conv5x5_wgrad(gy, x, s, in_affine=aff, affine_on_gy=True) if tr \
+                else ops.conv5x5_wgrad(x, gy, s, in_affine=aff)
+        if ctx.needs_input_grad[4]:
+            gb = torch.zeros(w.shape[1 if tr else 0], dtype=gy.dtype, device=gy.device) \
+                if ctx.bias_grad == BIAS_GRAD_ZERO else ops.channel_sum(gy)
+        return gx, dg, db, gw, gb, None, None, None, None, None, None, None, None, None
 
 
 class BiasActFn(Function):
@@ -192,8 +280,21 @@ def conv_transpose5x5(x, w, bias, stride, bias_grad=BIAS_GRAD_COMPUTE):
     return ConvT5x5Fn.apply(x, w, bias, stride, bias_grad)
 
 
-def batch_norm_act(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, act=ops.ACT_NONE):
-    return BNActFn.apply(x, gamma, beta, running_mean, running_var, eps, momentum, act)
+def batch_norm_act(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, act=ops.ACT_NONE, stats=None):
+    return BNActFn.apply(x, gamma, beta, running_mean, running_var, eps, momentum, act,
+                         stats if stats is not None and stats.numel() else None)
+
+
+def conv_with_stats(x, w, bias, stride, transposed=False, bias_grad=BIAS_GRAD_COMPUTE):
+    """(y, statistics slots of y) -- see ConvStatsFn."""
+    return ConvStatsFn.apply(x, w, bias, stride, transposed, bias_grad)
+
+
+def bn_act_conv(x, gamma, beta, running_mean, running_var, eps, momentum, act, w, bias, stride, transposed=False,
+                bias_grad=BIAS_GRAD_COMPUTE, stats_in=None):
+    """conv(act(BN_train(x))) with nothing materialised in between -- see BNConvFn.  Returns (y, stats of y)."""
+    return BNConvFn.apply(x, gamma, beta, w, bias, running_mean, running_var, eps, momentum, act, stride, transposed,
+                          bias_grad, stats_in)
 
 
 def bias_act(x, bias, kind):

@@ -79,13 +79,17 @@ class _HipBatchNormMixin:
         self._nbt_pending = 0
         self.register_state_dict_pre_hook(_flush_nbt)
 
-    def forward(self, x):
+    def _note_forward(self):
         if not self.training:
             raise RuntimeError("HipBatchNorm: eval-mode (running-statistics) normalisation is not part "
                                "of the reference's path and is not implemented")
         self._nbt_pending += 1     # num_batches_tracked, materialised lazily (no launch per call)
+
+    def forward(self, x, stats=None):
+        """``stats``: statistics slots left by the producing convolution (skips the statistics pass)."""
+        self._note_forward()
         return F.batch_norm_act(x.contiguous(), self.weight, self.bias, self.running_mean, self.running_var,
-                                self.eps, self.momentum, self.act)
+                                self.eps, self.momentum, self.act, stats)
 
     def _load_from_state_dict(self, *a, **k):
         self._nbt_pending = 0
@@ -153,12 +157,64 @@ class HipLinear(nn.Linear):
 
 
 # --------------------------------------------------------------- building blocks
+# Conv <-> BatchNorm fusion: inside a chain conv -> BN -> act -> conv -> ... the statistics of every
+# BatchNorm come from the producing convolution's epilogue, and its normalise + activation are applied by the
+# CONSUMING convolution while it loads -- the normalised tensor of an inner layer is never written.  False: every
+# BatchNorm runs its own two passes (the round-1 path; tests compare the two).
+FUSE_CONV_BN = True
+
+
+def run_conv_bn_chain(mods, x):
+    """Forward of [conv | transposed conv | HipBatchNorm2d | FusedIntoBN placeholder] modules in order, fused as
+    above; a BatchNorm that is last in the chain (its consumer is not one of these convolutions) is materialised,
+    still without its statistics pass when the producer left statistics."""
+    pending, stats = None, None          # BatchNorm not applied yet; statistics slots of the current x
+
+    def flush(t):
+        nonlocal pending, stats
+        if pending is not None:
+            t = pending(t, stats=stats)
+            pending, stats = None, None
+        return t
+    for m in mods:
+        if isinstance(m, (HipConv2d, HipConvTranspose2d)):
+            tr = isinstance(m, HipConvTranspose2d)
+            mode = F.BIAS_GRAD_ZERO if m.bn_shadowed else F.BIAS_GRAD_COMPUTE
+            if pending is not None:
+                bn = pending
+                bn._note_forward()
+                x, stats = F.bn_act_conv(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum,
+                                         bn.act, m.weight, m.bias, m.stride[0], tr, mode, stats)
+                pending = None
+            else:
+                x, stats = F.conv_with_stats(x.contiguous(), m.weight, m.bias, m.stride[0], tr, mode)
+        elif isinstance(m, HipBatchNorm2d):
+            x = flush(x)
+            pending = m
+        elif isinstance(m, FusedIntoBN):
+            continue
+        else:
+            x = flush(x)
+            x, stats = m(x), None
+    return flush(x)
+
+
+class FusedChain(nn.Sequential):
+    """nn.Sequential with the reference's indices (``features.0`` ... ``features.8``, ``convs.0`` ...), run fused.
+    (The class name must contain neither "Conv" nor "BatchNorm": weights_init matches class names, model.py:8-14.)"""
+
+    def forward(self, x):
+        if not FUSE_CONV_BN:
+            return super().forward(x)
+        return run_conv_bn_chain(list(self), x)
+
+
 def _enc_trunk(cin, width):
     chans = [cin, width, 2 * width, 4 * width]
     layers = []
     for a, b in zip(chans[:-1], chans[1:]):
         layers += [HipConv2d(a, b, 2), HipBatchNorm2d(b, ops.ACT_RELU), FusedIntoBN("ReLU")]
-    return nn.Sequential(*layers)
+    return FusedChain(*layers)
 
 
 def _latent_hw(opt):
@@ -197,6 +253,10 @@ class _DecoderMixin:
         bs = code.size(0)
         h = self.preprocess(code).view(-1, n_z[0], n_z[1], n_z[2])
         zh, zw = n_z[1], n_z[2]          # (8, 8) in the reference: the literals of model.py:558-564
+        if FUSE_CONV_BN:                 # deconv1 -> act1 -> deconv2 -> act2 -> deconv3 -> act3 -> deconv4 as one fused chain
+            h = run_conv_bn_chain([self.deconv1, *self.act1, self.deconv2, *self.act2, self.deconv3, *self.act3,
+                                   self.deconv4], h.contiguous())
+            return self.activation(h)
         h = self.act1(self.deconv1(h, output_size=(bs, 256, 2 * zh, 2 * zw)))
         h = self.act2(self.deconv2(h, output_size=(bs, 128, 4 * zh, 4 * zw)))
         h = self.act3(self.deconv3(h, output_size=(bs, 32, 8 * zh, 8 * zw)))
@@ -252,7 +312,7 @@ class Discriminator_celeba(nn.Module):
         layers = []
         for a, b, s in spec:
             layers += [HipConv2d(a, b, s), HipBatchNorm2d(b, ops.ACT_LRELU), FusedIntoBN("LeakyReLU(0.2)")]
-        self.convs = nn.Sequential(*layers)
+        self.convs = FusedChain(*layers)
         self.lth_features = nn.Sequential(HipLinear(dim, 2048), HipLeakyReLU())
         self.sigmoid_output = nn.Sequential(HipLinear(2048, 1), HipSigmoid())
 

@@ -99,6 +99,7 @@ def reserve_workspace(nbytes, device):
 # (a few microseconds); inside one -- the trainer opens it around an iteration, where it
 # alone decides when weights change -- a pack is reused until `invalidate_packed_filters()`.
 USE_PACKED_FILTERS = True
+FP32_CONV_STATS = False     # see conv5x5_fwd
 # Arithmetic of the three convolution kernels (forward, transposed = data gradient, weight gradient):
 #   "bf16x6"  the product DEFAULT: every fp32 operand split exactly into 3 bf16 planes (8 + 8 + 8 mantissa bits),
 #             the 6 plane products whose indices sum to < 3 issued on the bf16 MFMA, fp32 accumulation:
@@ -201,7 +202,38 @@ def _packed_filter(lib, w, cout, cin, transposed, stride):
     return buf
 
 
-def conv5x5_fwd(x, w, bias, stride):
+def conv_fusable(transposed, cin, cout, stride):
+    """Whether the kernel of this layer (under the active arithmetic) applies a producer's BatchNorm + activation
+    while it loads its input and can leave output statistics (include/vaegan_hip.h, vg_conv_fusion)."""
+    return bool(_planes()) and bool(_lib.load().vg_conv5x5_bf16split_fusable(1 if transposed else 0, cin, cout, stride))
+
+
+def _fusion_struct(x, in_affine, stats):
+    """ctypes vg_conv_fusion (or None) + the tensors it points at (kept alive by the caller)."""
+    if in_affine is None and stats is None:
+        return None
+    f = _lib.ConvFusion()
+    if in_affine is not None:
+        scale, shift, act = in_affine
+        _req(scale, "in_scale"), _req(shift, "in_shift")
+        if scale.numel() != x.shape[1] or shift.numel() != x.shape[1]:
+            raise RuntimeError("in_affine: one coefficient per input channel")
+        f.in_scale, f.in_shift, f.in_act = scale.data_ptr(), shift.data_ptr(), int(act)
+    if stats is not None:
+        f.stats, f.stats_floats = stats.data_ptr(), stats.numel()
+    return f
+
+
+def _materialize(x, in_affine):
+    """act(x * scale[c] + shift[c]) as a tensor: the fallback for kernels that cannot apply it on load."""
+    return x if in_affine is None else affine_act(x, *in_affine)
+
+
+def conv5x5_fwd(x, w, bias, stride, in_affine=None, want_stats=False):
+    """``in_affine`` = (scale, shift, act): the input is act(x * scale[c] + shift[c]) -- the producing layer's
+    train-mode BatchNorm + activation -- applied on load where the kernel can, materialised first where it cannot.
+    ``want_stats``: returns (y, stats) with per-channel partial sums of y for `bn_finalize_stats`, or (y, None)
+    when this layer's kernel cannot emit them."""
     lib = _lib.load()
     _req(x, "x"), _req(w, "w")
     B, Cin, H, W = x.shape
@@ -212,29 +244,51 @@ def conv5x5_fwd(x, w, bias, stride):
         _req(bias, "bias")
     OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
     y = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
+    stats = None
     if _planes() and Cin % 16 == 0:
+        fus = conv_fusable(False, Cin, Cout, stride)
+        if in_affine is not None and not fus:
+            x, in_affine = _materialize(x, in_affine), None
+        if want_stats and fus:
+            n = lib.vg_conv5x5_fwd_bf16split_stats_floats(B, Cin, H, W, Cout, stride)
+            stats = torch.empty(n, dtype=torch.float32, device=x.device) if n else None
+        f = _fusion_struct(x, in_affine, stats)
         pk = _packed_filter(lib, w, Cout, Cin, 2, stride)      # the stride-2 kernel has its own step order
         need = lib.vg_conv5x5_fwd_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride)    # split-K slabs, deep-K layers only
         ws = workspace(need, x.device) if need else None
         with _timed(("conv_fwd", B, Cin, H, W, Cout, stride)):
             check(lib.vg_conv5x5_fwd_bf16split(x.data_ptr(), pk.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W,
-                                            Cout, stride, _planes(), _ptr(ws), ws.numel() if need else 0, _stream()),
+                                            Cout, stride, _planes(), _ptr(ws), ws.numel() if need else 0,
+                                            __import__("ctypes").byref(f) if f is not None else None, _stream()),
                   "vg_conv5x5_fwd_bf16split")
-        return y
+        return (y, stats) if want_stats else y
+    x = _materialize(x, in_affine)
     if USE_PACKED_FILTERS:
         pk = _packed_filter(lib, w, Cout, Cin, 0, stride)
+        # The exact-fp32 kernel can leave the next BatchNorm's statistics too (vg_conv5x5_fwd_packed_stats), but on the
+        # 3-channel first layers -- 16 384 slots for 32 channels at B = 128 -- writing and reducing the slots costs more
+        # than the one pass over the output it saves (measured: +0.26 ms per iteration): opt-in only.
+        n = lib.vg_conv5x5_fwd_packed_stats_floats(B, Cin, H, W, Cout, stride) if (want_stats and FP32_CONV_STATS) else 0
+        if n:
+            stats = torch.empty(n, dtype=torch.float32, device=x.device)
+            with _timed(("conv_fwd", B, Cin, H, W, Cout, stride)):
+                check(lib.vg_conv5x5_fwd_packed_stats(x.data_ptr(), pk.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H,
+                                                      W, Cout, stride, stats.data_ptr(), n, _stream()),
+                      "vg_conv5x5_fwd_packed_stats")
+            return y, stats
         with _timed(("conv_fwd", B, Cin, H, W, Cout, stride)):
             check(lib.vg_conv5x5_fwd_packed(x.data_ptr(), pk.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W,
                                             Cout, stride, _stream()), "vg_conv5x5_fwd_packed")
-        return y
+        return (y, None) if want_stats else y
     with _timed(("conv_fwd", B, Cin, H, W, Cout, stride)):
         check(lib.vg_conv5x5_fwd(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W, Cout,
                                  stride, _stream()), "vg_conv5x5_fwd")
-    return y
+    return (y, None) if want_stats else y
 
 
-def convT5x5_fwd(x, w, bias, stride):
-    """w is (Cin, Cout, 5, 5); output is (B, Cout, stride*H, stride*W)."""
+def convT5x5_fwd(x, w, bias, stride, in_affine=None, want_stats=False):
+    """w is (Cin, Cout, 5, 5); output is (B, Cout, stride*H, stride*W).  ``in_affine`` / ``want_stats``: see
+    `conv5x5_fwd`."""
     lib = _lib.load()
     _req(x, "x"), _req(w, "w")
     B, Cin, H, W = x.shape
@@ -246,29 +300,41 @@ def convT5x5_fwd(x, w, bias, stride):
     y = torch.empty((B, Cout, H * stride, W * stride), dtype=torch.float32, device=x.device)
     # stride 1 with <= 4 output channels runs the direct VALU kernel on the plain layout
     thin = stride == 1 and Cout <= 4
+    stats = None
     if _planes() and Cin % 16 == 0 and not thin:
+        fus = conv_fusable(True, Cin, Cout, stride)
+        if in_affine is not None and not fus:
+            x, in_affine = _materialize(x, in_affine), None
+        if want_stats and fus:
+            n = lib.vg_convT5x5_fwd_bf16split_stats_floats(B, Cin, H, W, Cout, stride)
+            stats = torch.empty(n, dtype=torch.float32, device=x.device) if n else None
+        f = _fusion_struct(x, in_affine, stats)
         pk = _packed_filter(lib, w, Cout, Cin, 3, stride)
         need = lib.vg_convT5x5_fwd_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride)   # split-K slabs, small grids only
         ws = workspace(need, x.device) if need else None
         with _timed(("convT_fwd", B, Cin, H, W, Cout, stride)):
             check(lib.vg_convT5x5_fwd_bf16split(x.data_ptr(), pk.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W,
-                                             Cout, stride, _planes(), _ptr(ws), ws.numel() if need else 0, _stream()),
+                                             Cout, stride, _planes(), _ptr(ws), ws.numel() if need else 0,
+                                             __import__("ctypes").byref(f) if f is not None else None, _stream()),
                   "vg_convT5x5_fwd_bf16split")
-        return y
+        return (y, stats) if want_stats else y
+    x = _materialize(x, in_affine)
     if USE_PACKED_FILTERS and not thin:
         pk = _packed_filter(lib, w, Cout, Cin, 1, stride)
         with _timed(("convT_fwd", B, Cin, H, W, Cout, stride)):
             check(lib.vg_convT5x5_fwd_packed(x.data_ptr(), pk.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W,
                                              Cout, stride, _stream()), "vg_convT5x5_fwd_packed")
-        return y
+        return (y, None) if want_stats else y
     with _timed(("convT_fwd", B, Cin, H, W, Cout, stride)):
         check(lib.vg_convT5x5_fwd(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W, Cout,
                                   stride, _stream()), "vg_convT5x5_fwd")
-    return y
+    return (y, None) if want_stats else y
 
 
-def conv5x5_wgrad(x, gy, stride, out=None):
-    """dw[Cout,Cin,5,5] for y = conv(x, w, stride); x (B,Cin,H,W), gy (B,Cout,OH,OW)."""
+def conv5x5_wgrad(x, gy, stride, out=None, in_affine=None, affine_on_gy=False):
+    """dw[Cout,Cin,5,5] for y = conv(x, w, stride); x (B,Cin,H,W), gy (B,Cout,OH,OW).  ``in_affine`` = (scale, shift,
+    act): the operand x -- or gy when ``affine_on_gy`` (the weight gradient of a transposed convolution passes the
+    layer's input there) -- is read as act(v * scale[c] + shift[c]), on load where the kernel can."""
     lib = _lib.load()
     _req(x, "x"), _req(gy, "gy")
     B, Cin, H, W = x.shape
@@ -283,10 +349,17 @@ def conv5x5_wgrad(x, gy, stride, out=None):
         need = lib.vg_conv5x5_wgrad_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride, _planes())    # 0: shape not taken
         if need:
             ws = workspace(need, x.device)
+            sc, sh, act = in_affine if in_affine is not None else (None, None, 0)
             with _timed(("conv_wgrad", B, Cin, H, W, Cout, stride)):
                 check(lib.vg_conv5x5_wgrad_bf16split(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout, stride,
-                                                  _planes(), ws.data_ptr(), ws.numel(), _stream()), "vg_conv5x5_wgrad_bf16split")
+                                                  _planes(), ws.data_ptr(), ws.numel(), _ptr(sc), _ptr(sh), int(act),
+                                                  1 if affine_on_gy else 0, _stream()), "vg_conv5x5_wgrad_bf16split")
             return dw
+    if in_affine is not None:      # the exact-fp32 kernel takes the operand as a tensor
+        if affine_on_gy:
+            gy = _materialize(gy, in_affine)
+        else:
+            x = _materialize(x, in_affine)
     need = lib.vg_conv5x5_wgrad_workspace_bytes(B, Cin, H, W, Cout, stride)
     ws = workspace(need, x.device)
     with _timed(("conv_wgrad", B, Cin, H, W, Cout, stride)):
@@ -321,6 +394,52 @@ def bn_act_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, act):
                             _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), B, C, HW, eps, momentum, act,
                             ws.data_ptr(), ws.numel(), _stream()), "vg_bn_act_fwd")
     return y, mean, invstd
+
+
+def bn_finalize_stats(stats, count, gamma, beta, running_mean, running_var, eps, momentum):
+    """Coefficients of a train-mode BatchNorm from a convolution's statistics slots (``stats`` from
+    conv5x5_fwd / convT5x5_fwd with want_stats): (mean, invstd, scale, shift); running statistics updated in place."""
+    lib = _lib.load()
+    _req(stats, "stats"), _req(gamma, "gamma"), _req(beta, "beta")
+    C = gamma.numel()
+    nslots = stats.numel() // (2 * C)
+    out = torch.empty((4, C), dtype=torch.float32, device=gamma.device)
+    mean, invstd, scale, shift = out[0], out[1], out[2], out[3]
+    ws = workspace(lib.vg_bn_workspace_bytes(C), gamma.device)
+    check(lib.vg_bn_finalize_stats(stats.data_ptr(), nslots, C, float(count), gamma.data_ptr(), beta.data_ptr(),
+                                   _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(),
+                                   scale.data_ptr(), shift.data_ptr(), eps, momentum, ws.data_ptr(), ws.numel(), _stream()),
+          "vg_bn_finalize_stats")
+    return mean, invstd, scale, shift
+
+
+def bn_stats(x, gamma, beta, running_mean, running_var, eps, momentum):
+    """The same coefficients from a pass over x (layers whose producer leaves no statistics)."""
+    lib = _lib.load()
+    _req(x, "x"), _req(gamma, "gamma"), _req(beta, "beta")
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    out = torch.empty((4, C), dtype=torch.float32, device=x.device)
+    mean, invstd, scale, shift = out[0], out[1], out[2], out[3]
+    ws = workspace(lib.vg_bn_workspace_bytes(C), x.device)
+    check(lib.vg_bn_stats(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(running_mean), _ptr(running_var),
+                          mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), B, C, HW, eps, momentum,
+                          ws.data_ptr(), ws.numel(), _stream()), "vg_bn_stats")
+    return mean, invstd, scale, shift
+
+
+def affine_act(x, scale, shift, act):
+    """act(x * scale[c] + shift[c]) (the normalise pass of a BatchNorm whose coefficients are known)."""
+    lib = _lib.load()
+    _req(x, "x"), _req(scale, "scale"), _req(shift, "shift")
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    if HW % 4:
+        raise RuntimeError("affine_act: H*W must be a multiple of 4")
+    y = torch.empty_like(x)
+    check(lib.vg_affine_act(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), B, C, HW, int(act), _stream()),
+          "vg_affine_act")
+    return y
 
 
 def bn_act_bwd(gy, x, gamma, beta, mean, invstd, act, need_param_grads=True):

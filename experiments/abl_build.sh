@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 C=disentangle_mlp_amd/csrc
 OBJS=$(ls $C/build/*.o | grep -v conv_ring.o)
 for bits in "$@"; do
-  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -I$C -Wno-unused-result -DVG_RING_ABL=$bits -c $C/conv_ring.hip -o experiments/abl/ring_$bits.o &&
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -I$C -Wno-unused-result -mllvm -pragma-unroll-threshold=131072 -DVG_RING_ABL=$bits -c $C/conv_ring.hip -o experiments/abl/ring_$bits.o &&
     /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o experiments/abl/libabl_$bits.so experiments/abl/ring_$bits.o $OBJS ) &
 done
 wait

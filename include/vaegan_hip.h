@@ -74,6 +74,14 @@ int vg_conv5x5_fwd_packed(const float* x, const float* packed, const float* bias
                           int B, int Cin, int H, int W, int Cout, int stride, void* stream);
 int vg_convT5x5_fwd_packed(const float* x, const float* packed, const float* bias, float* y,
                            int B, int Cin, int H, int W, int Cout, int stride, void* stream);
+/* vg_conv5x5_fwd_packed that also leaves the statistics of its output for the BatchNorm that follows
+ * (vg_conv_fusion.stats semantics: [slot][Cout][2] partial sums; vg_bn_finalize_stats consumes them) -- the
+ * 3-channel first layers (model.py:389-390, 450-451), whose 67 MB / 34 MB outputs would otherwise be read once
+ * more only to be summed.  `stats` holds vg_conv5x5_fwd_packed_stats_floats(...) floats. */
+size_t vg_conv5x5_fwd_packed_stats_floats(int B, int Cin, int H, int W, int Cout, int stride);
+int vg_conv5x5_fwd_packed_stats(const float* x, const float* packed, const float* bias, float* y,
+                                int B, int Cin, int H, int W, int Cout, int stride,
+                                float* stats, size_t stats_floats, void* stream);
 
 /* Split-bf16 arithmetic of vg_conv5x5_fwd / vg_convT5x5_fwd: every fp32 operand is split
  * into `planes` bf16 values and the products whose plane indices sum to < planes are evaluated on the bf16
@@ -90,25 +98,49 @@ int vg_convT5x5_fwd_packed(const float* x, const float* packed, const float* bia
  * Stride 2 runs on the 8-wavefront kernel of conv_ring.hip (both MFMA operands from LDS, the filter through a
  * global_load_lds DMA ring); layers whose tile grid would leave CUs idle split their input channels over
  * workgroups and sum the partial outputs in a fixed order: query the workspace (0 for most shapes). */
+/* Fused BatchNorm around a stride-2 split-bf16 convolution (replaces the separate statistics and
+ * normalise passes of F.batch_norm reached from model.py:451-458, 496-505, 390-400):
+ *   in_scale / in_shift / in_act: the input is read as act(x * in_scale[c] + in_shift[c]) -- the producing layer's
+ *     train-mode BatchNorm (scale = gamma * invstd, shift = beta - mean * scale) and activation (VG_ACT_*) applied
+ *     while the patch is staged; zero padding pads the activated tensor.  NULL: the input is used as it is.
+ *   stats: per-channel partial sums of THIS layer's output, [slot][Cout][2] floats (sum y, sum y^2 over the slot's
+ *     pixels, bias included), `stats_floats` = vg_conv*_stats_floats(...) of them; vg_bn_finalize_stats turns them
+ *     into the next BatchNorm's coefficients.  NULL: none.
+ * vg_conv5x5_bf16split_fusable says whether a layer's kernel takes a non-empty fusion; *_stats_floats returns 0 for
+ * layers that cannot emit statistics (other kernels, K-split layers). */
+typedef struct vg_conv_fusion {
+  const float* in_scale;
+  const float* in_shift;
+  int in_act;
+  float* stats;
+  size_t stats_floats;
+} vg_conv_fusion;
+int vg_conv5x5_bf16split_fusable(int transposed, int Cin, int Cout, int stride);
+size_t vg_conv5x5_fwd_bf16split_stats_floats(int B, int Cin, int H, int W, int Cout, int stride);
+size_t vg_convT5x5_fwd_bf16split_stats_floats(int B, int Cin, int H, int W, int Cout, int stride);
 size_t vg_conv5x5_packed_bf16split_bytes(int Cout, int Cin, int planes);
 int vg_conv5x5_pack_bf16split(const float* w, void* packed, int Cout, int Cin, int transposed, int stride,
                            int planes, void* stream);
 size_t vg_conv5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride);
 int vg_conv5x5_fwd_bf16split(const float* x, const void* packed, const float* bias, float* y,
                           int B, int Cin, int H, int W, int Cout, int stride, int planes,
-                          void* workspace, size_t workspace_bytes, void* stream);
+                          void* workspace, size_t workspace_bytes, const vg_conv_fusion* fuse, void* stream);
 size_t vg_convT5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride);
 int vg_convT5x5_fwd_bf16split(const float* x, const void* packed, const float* bias, float* y,
                            int B, int Cin, int H, int W, int Cout, int stride, int planes,
-                           void* workspace, size_t workspace_bytes, void* stream);
-/* vg_conv5x5_wgrad in the same opt-in arithmetic.  The reduction runs over images in groups of 16
- * (operands re-laid batch-innermost inside the call; B is zero-padded to a multiple of 16); needs
- * OH % 4 == 0 (planes = 2) or OH % 2 == 0 (planes = 3) and OW % 8 == 0 -- the workspace query returns 0 for shapes it does not take
- * (use vg_conv5x5_wgrad).  workspace: 16-byte aligned. */
+                           void* workspace, size_t workspace_bytes, const vg_conv_fusion* fuse, void* stream);
+/* vg_conv5x5_wgrad in the same arithmetic.  The reduction runs over images in groups of 16: gy is re-laid
+ * batch-innermost inside the call (B zero-padded to a multiple of 16), x is staged straight from NCHW; needs
+ * OW % 8 == 0 -- the workspace query returns 0 for shapes it does not take (use vg_conv5x5_wgrad).
+ * workspace: 16-byte aligned. */
 size_t vg_conv5x5_wgrad_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride, int planes);
 int vg_conv5x5_wgrad_bf16split(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W,
                             int Cout, int stride, int planes, void* workspace, size_t workspace_bytes,
+                            const float* in_scale, const float* in_shift, int in_act, int affine_on_gy,
                             void* stream);
+/* in_scale / in_shift / in_act: one operand is read as act(v * scale[c] + shift[c]) (vg_conv_fusion semantics) --
+ * x (Cin coefficients) when affine_on_gy == 0, gy (Cout coefficients; the weight gradient of a transposed
+ * convolution passes the layer's input there) otherwise.  NULL, NULL, 0, 0: both operands as they are. */
 
 /* dw[Cout,Cin,5,5] = sum_{b,oh,ow} gy[b,co,oh,ow] * x[b,ci,s*oh+kh-2,s*ow+kw-2].
  * Weight gradient of nn.Conv2d (autograd of model.py:450...; new_betavaegan.py:103,121)
@@ -144,6 +176,23 @@ int vg_bn_act_bwd(const float* gy, const float* x, const float* gamma, const flo
                   float* gx, float* dgamma, float* dbeta,
                   int B, int C, int HW, int act,
                   void* workspace, size_t workspace_bytes, void* stream);
+/* Fused-BatchNorm helpers.  vg_bn_finalize_stats turns a convolution's statistics slots
+ * ([nslots][C][2] floats: vg_conv_fusion.stats) into the coefficients of the train-mode BatchNorm that follows it
+ * -- save_mean / save_invstd for backward, scale = gamma * invstd and shift = beta - mean * scale for the consumer's
+ * in_scale / in_shift -- and updates the running statistics (momentum, unbiased variance) as vg_bn_act_fwd does;
+ * count = B * H * W.  vg_bn_stats does the same from a pass over x (layers whose producer cannot emit statistics).
+ * vg_affine_act materialises y = act(x * scale[c] + shift[c]) (HW % 4 == 0) for consumers that cannot apply the
+ * coefficients while they load. */
+int vg_bn_finalize_stats(const float* stats, int nslots, int C, double count, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                         float* scale, float* shift, float eps, float momentum,
+                         void* workspace, size_t workspace_bytes, /* vg_bn_workspace_bytes(C) */ void* stream);
+int vg_bn_stats(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                float* save_mean, float* save_invstd, float* scale, float* shift, int B, int C, int HW,
+                float eps, float momentum, void* workspace, size_t workspace_bytes, void* stream);
+int vg_affine_act(const float* x, const float* scale, const float* shift, float* y, int B, int C, int HW, int act,
+                  void* stream);
+
 
 /* ---- elementwise activations ------------------------------------------------
  * LeakyReLU(0.2) after lth_features (model.py:404), tanh after deconv4

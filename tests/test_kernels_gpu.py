@@ -624,3 +624,68 @@ def test_bf16x6_is_fp32_equivalent(H, B, Cin, Cout, Hs, Ws, stride):
         assert_close(H.conv5x5_wgrad(x.cuda(), gy.cuda(), stride), gw_ref, 3e-6, "bf16x6 wgrad")
     finally:
         H.CONV_ARITH = prev_arith
+
+
+# ------------------------------------------------------------------ Conv <-> BatchNorm fusion
+@pytest.mark.parametrize("transposed,B,Cin,Cout,Hs,Ws,act", [
+    (False, 4, 32, 128, 16, 16, "lrelu"), (False, 3, 48, 70, 14, 10, "relu"), (False, 64, 128, 256, 16, 16, "lrelu"),
+    (True, 4, 256, 128, 8, 8, "relu"), (True, 3, 64, 256, 16, 16, "relu"), (True, 2, 128, 32, 8, 8, "relu"),
+    (False, 2, 3, 8, 16, 16, "none")])
+def test_conv_input_affine_and_output_stats(H, B, Cin, Cout, Hs, Ws, transposed, act):
+    """in_affine: conv(act(x * scale[c] + shift[c])) applied on load == the same convolution of the materialised
+    tensor (oracle in fp64), including the zero padding of the ACTIVATED tensor; want_stats: the statistics slots
+    reduce to the per-channel sum / sum of squares of the output.  Layers whose kernel cannot fuse (3 input channels,
+    thin transposed outputs) take the fallback inside ops and must give the same numbers."""
+    code = {"none": 0, "relu": 1, "lrelu": 2}[act]
+    g = torch.Generator().manual_seed(70)
+    x = torch.randn(B, Cin, Hs, Ws, generator=g)
+    scale, shift = 0.5 + torch.rand(Cin, generator=g), torch.randn(Cin, generator=g)
+    w = 0.05 * torch.randn(*((Cin, Cout, 5, 5) if transposed else (Cout, Cin, 5, 5)), generator=g)
+    bias = torch.randn(Cout, generator=g)
+    xa = x.double() * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    xa = {"none": xa, "relu": xa.clamp(min=0), "lrelu": torch.where(xa > 0, xa, 0.2 * xa)}[act]
+    ref = (O.convT5x5 if transposed else O.conv5x5)(xa, w, bias, 2)
+    conv = H.convT5x5_fwd if transposed else H.conv5x5_fwd
+    H.FP32_CONV_STATS = True          # also exercise the exact-fp32 kernel's statistics epilogue (opt-in in the product)
+    try:
+        y, stats = conv(x.cuda(), w.cuda(), bias.cuda(), 2, in_affine=(scale.cuda(), shift.cuda(), code), want_stats=True)
+    finally:
+        H.FP32_CONV_STATS = False
+    assert_close(y, ref, CONV_TOL, "conv with input affine")
+    if stats is not None:
+        st = stats.view(-1, Cout, 2).double().sum(0).cpu()
+        assert_close(st[:, 0], ref.sum(dim=(0, 2, 3)), 2e-5, "stats: sum")          # fp32 partial sums per tile
+        assert_close(st[:, 1], (ref ** 2).sum(dim=(0, 2, 3)), 2e-5, "stats: sum of squares")
+    else:
+        assert not H.conv_fusable(transposed, Cin, Cout, 2) or B * Hs * Ws <= 64 * 64 * 8      # unfusable or K-split
+    # weight gradient with the same operand transform (x for a convolution, the gy slot for a transposed one)
+    gy = torch.randn(*ref.shape, generator=g)
+    if transposed:
+        _, gw_ref = O.convT5x5_grads(xa, w, gy, 2)
+        gw = H.conv5x5_wgrad(gy.cuda(), x.cuda(), 2, in_affine=(scale.cuda(), shift.cuda(), code), affine_on_gy=True)
+    else:
+        _, gw_ref = O.conv5x5_grads(xa, w, gy, 2)
+        gw = H.conv5x5_wgrad(x.cuda(), gy.cuda(), 2, in_affine=(scale.cuda(), shift.cuda(), code))
+    assert_close(gw, gw_ref, CONV_TOL, "wgrad with input affine")
+
+
+def test_bn_coefficients_from_stats_and_from_pass(H):
+    """vg_bn_finalize_stats (slots from a convolution epilogue) and vg_bn_stats (one pass over x) give the
+    coefficients, saved statistics and running-statistics update of train-mode batch norm (oracle: F.batch_norm)."""
+    g = torch.Generator().manual_seed(71)
+    B, Cin, Cout, Hs = 8, 32, 128, 16
+    x, w, b = torch.randn(B, Cin, Hs, Hs, generator=g), 0.05 * torch.randn(Cout, Cin, 5, 5, generator=g), torch.randn(Cout, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g)
+    y, stats = H.conv5x5_fwd(x.cuda(), w.cuda(), b.cuda(), 2, want_stats=True)
+    assert stats is not None
+    ref = O.bn_act(O.conv5x5(x, w, b, 2), gamma, beta, "lrelu")
+    for how in ("slots", "pass"):
+        rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+        if how == "slots":
+            mean, invstd, scale, shift = H.bn_finalize_stats(stats, B * 8 * 8, gamma.cuda(), beta.cuda(), rm, rv, 1e-5, 0.1)
+        else:
+            mean, invstd, scale, shift = H.bn_stats(y, gamma.cuda(), beta.cuda(), rm, rv, 1e-5, 0.1)
+        assert_close(rm, ref["rm"], 3e-6, how + " running mean")
+        assert_close(rv, ref["rv"], 3e-6, how + " running var")
+        out = H.affine_act(y, scale, shift, 2)
+        assert_close(out, ref["y"], 3e-6, how + " normalised output")
