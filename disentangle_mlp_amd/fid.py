@@ -16,10 +16,13 @@ pool_3 activations (fid.py:181-183) and the Frechet distance with a Schur-based
 
 File contract kept: ``.npz`` statistics with keys ``mu`` and ``sigma`` (fid.py:287-290),
 ``get_fid(path_data, path_pretrained, inception="", lowprofile=False)`` (fid.py:320-323).
-The Inception network (fid.py:34-105: a TensorFlow GraphDef downloaded at run time) is NOT
-part of this repo and cannot be fetched here, so image folders need a ``feature_extractor``
-callable (uint8-range float images [n,h,w,3] -> [n,2048]); without one ``get_fid`` accepts
-``.npz`` statistics on both sides and raises otherwise.  Absolute FID of images: unpinned.
+The Inception pool_3 network is disentangle_mlp_amd/inception.py (the FID Inception-v3 of scoring/inception.py
+on the device).  Its pretrained weights (fid.py:268-283 downloads a TensorFlow GraphDef; scoring/inception.py:13
+the PyTorch port of the same weights) are NOT part of this repo and cannot be fetched here: pass the
+``pt_inception-2015-12-05`` state_dict file as ``inception=`` (the reference's ``inception_path`` argument), or any
+``feature_extractor`` callable (images [n,h,w,3] with values 0..255 -> [n,2048]); without either ``get_fid`` accepts
+``.npz`` statistics on both sides and raises otherwise.  Absolute FID of images: unpinned (no weights, no reference
+statistics offline).
 """
 import os
 import pathlib
@@ -143,11 +146,31 @@ def _handle_path(path, feature_extractor, device, batch_size=50):
     return st.finalize()
 
 
+def _find_inception_weights(inception_path):
+    """The reference's ``inception_path`` is a directory or file of the Inception model (fid.py:268-283); here: the
+    ``pt_inception-2015-12-05*.pth`` state_dict, given directly or looked up in a directory."""
+    if not inception_path:
+        return None
+    p = pathlib.Path(inception_path)
+    if p.is_file():
+        return str(p)
+    if p.is_dir():
+        hits = sorted(p.glob("pt_inception-2015-12-05*.pth"))
+        if hits:
+            return str(hits[0])
+    raise RuntimeError(f"no Inception state_dict (pt_inception-2015-12-05*.pth) at {inception_path!r}")
+
+
 def calculate_fid_given_paths(paths, inception_path="", low_profile=False, feature_extractor=None, device="cuda"):
     """fid.py:303-317."""
     for p in paths:
         if not os.path.exists(p):
             raise RuntimeError("Invalid path: %s" % p)
+    if feature_extractor is None and not all(str(p).endswith(".npz") for p in paths):
+        weights = _find_inception_weights(inception_path)
+        if weights is not None:
+            from .inception import InceptionFeatureExtractor
+            feature_extractor = InceptionFeatureExtractor(weights, device=device)
     m1, s1 = _handle_path(paths[0], feature_extractor, device)
     m2, s2 = _handle_path(paths[1], feature_extractor, device)
     return calculate_frechet_distance(m1, s1, m2, s2, device=device)
