@@ -285,9 +285,13 @@ def main():
             # the roof of the split arithmetics: each fp32 multiply-add costs `nprod` bf16 MFMA multiply-adds,
             # so the dense bf16 peak / nprod is what a perfect kernel of this arithmetic would reach
             peak = PEAK_BF16_MFMA_TFLOPS / nprod if split else PEAK_FP32_MFMA_TFLOPS
-            kname = {"conv_fwd": "conv5x5_bf16split_kernel", "convT_fwd": "conv5x5_bf16split_kernel",
-                     "conv_wgrad": "conv5x5_wgrad_bf16split_kernel"}[dominant[0]] if split else \
-                ("conv5x5_igemm_kernel" if dominant[0] != "conv_wgrad" else "conv5x5_wgrad_kernel")
+            if not split:
+                kname = "conv5x5_igemm_kernel" if dominant[0] != "conv_wgrad" else "conv5x5_wgrad_kernel"
+            elif dominant[0] == "conv_wgrad":
+                kname = "conv5x5_wgrad_split8_kernel"
+            else:      # stride 2 runs on the 8-wave ring kernel (conv_ring.hip), the rest on conv_bf16split.hip
+                kname = "conv5x5_ring_kernel" if ops.conv_fusable(dominant[0] == "convT_fwd", dominant[2], dominant[5],
+                                                                  dominant[6]) else "conv5x5_bf16split_kernel"
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                     "traffic_source": tsrc, "kernel": kname,
