@@ -68,6 +68,33 @@ class ConvT5x5Fn(Function):
         return gx, gw, gb, None, None
 
 
+class LinearFn(Function):
+    """nn.Linear (model.py:460-471, 402-408, 490-492) on the split-bf16 GEMM (ops.linear_*: same fp32-equivalent
+    arithmetic as the convolutions); a GEMM whose reduction length is not a multiple of 32 -- the weight gradient at
+    batches that are not -- goes to the vendor library."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        ctx.save_for_backward(x, w)
+        if ops.linear_split_ok(x.shape[1]):
+            return ops.linear_fwd(x, w, bias)
+        return torch.nn.functional.linear(x, w, bias)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.linear_dgrad(gy, w) if ops.linear_split_ok(gy.shape[1]) else gy @ w
+        if ctx.needs_input_grad[1]:
+            gw = ops.linear_wgrad(gy, x) if ops.linear_split_ok(gy.shape[0]) else gy.t() @ x
+        if ctx.needs_input_grad[2]:
+            gb = gy.sum(0)
+        return gx, gw, gb
+
+
 class BNActFn(Function):
     """Train-mode BatchNorm1d/2d + {none, ReLU, LeakyReLU(0.2)} -- model.py:451-452 etc.
     running_mean / running_var are updated in place by the kernel.  ``stats``: the statistics slots the producing
@@ -278,6 +305,10 @@ def conv5x5(x, w, bias, stride, bias_grad=BIAS_GRAD_COMPUTE):
 
 def conv_transpose5x5(x, w, bias, stride, bias_grad=BIAS_GRAD_COMPUTE):
     return ConvT5x5Fn.apply(x, w, bias, stride, bias_grad)
+
+
+def linear(x, w, bias):
+    return LinearFn.apply(x.contiguous(), w, bias)
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, act=ops.ACT_NONE, stats=None):

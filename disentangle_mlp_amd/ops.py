@@ -4,6 +4,8 @@ PyTorch is plumbing here: it owns device memory and the current HIP stream; ever
 arithmetic op below runs in libvaegan_hip.so.  Inputs must be CUDA (ROCm) fp32
 tensors -- there is deliberately no CPU path.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -366,6 +368,57 @@ def conv5x5_wgrad(x, gy, stride, out=None, in_affine=None, affine_on_gy=False):
         check(lib.vg_conv5x5_wgrad(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout, stride,
                                    ws.data_ptr(), ws.numel(), _stream()), "vg_conv5x5_wgrad")
     return dw
+
+
+# ------------------------------------------------------------------- Linear layers
+# The Linear GEMMs of the big layers (16384 <-> 2048, 128 -> 16384) on this package's split-bf16 GEMM
+# (csrc/gemm_split.hip) instead of the vendor fp32 GEMM.  Opt-in (VG_LINEAR_SPLIT=1 or ops.LINEAR_SPLIT = True): at
+# B = 128 the kernel measures level with the vendor library on the 16384 x 2048 layers (85-115 us against 88-107 us:
+# the weight is used once, so splitting it into planes costs as many VALU cycles as its 6 MFMA products), and only
+# wins on the decoder's 128 -> 16384 data gradient (34 us against 69 us) -- DESIGN.md section 4.
+LINEAR_SPLIT = os.environ.get("VG_LINEAR_SPLIT", "0") == "1"
+
+
+def _gemm_nt(A, B, bias, C, M, N, K, ars, aks, brs, bks):
+    lib = _lib.load()
+    need = lib.vg_gemm_nt_bf16split_workspace_bytes(M, N, K)
+    ws = workspace(need, A.device) if need else None
+    check(lib.vg_gemm_nt_bf16split(A.data_ptr(), B.data_ptr(), _ptr(bias), C.data_ptr(), M, N, K, ars, aks, brs, bks,
+                                   _planes(), _ptr(ws), ws.numel() if need else 0, _stream()), "vg_gemm_nt_bf16split")
+    return C
+
+
+def linear_split_ok(reduction):
+    """The split-bf16 GEMM takes a Linear GEMM when the active arithmetic is a split one and the reduction length
+    is a multiple of 32."""
+    return LINEAR_SPLIT and bool(_planes()) and reduction % 32 == 0
+
+
+def linear_fwd(x, w, bias):
+    """y = x W^T + bias (nn.Linear forward, model.py:460-471): x (M, K), w (N, K)."""
+    _req(x, "x"), _req(w, "w")
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    return _gemm_nt(x, w, bias, y, M, N, K, K, 1, K, 1)
+
+
+def linear_dgrad(gy, w):
+    """gx = gy W: gy (M, N), w (N, K) -> (M, K); the reduction runs over N, W is read with its row index contiguous."""
+    _req(gy, "gy"), _req(w, "w")
+    M, N = gy.shape
+    K = w.shape[1]
+    gx = torch.empty((M, K), dtype=torch.float32, device=gy.device)
+    return _gemm_nt(gy, w, None, gx, M, K, N, N, 1, 1, K)
+
+
+def linear_wgrad(gy, x):
+    """gW = gy^T x: gy (M, N), x (M, K) -> (N, K); the reduction runs over the batch M (both operands strided)."""
+    _req(gy, "gy"), _req(x, "x")
+    M, N = gy.shape
+    K = x.shape[1]
+    gw = torch.empty((N, K), dtype=torch.float32, device=gy.device)
+    return _gemm_nt(gy, x, None, gw, N, K, M, 1, N, 1, K)
 
 
 def channel_sum(g):
