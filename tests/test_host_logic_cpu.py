@@ -93,7 +93,8 @@ def _dp_worker(rank, world, port, batch, q):
             p.grad.add_(gi)                  # small tensors: accumulated into the flat views
     flat.finish()                            # no hook fired (no backward here): every bucket reduced now
     if rank == 0:
-        q.put(flat.gathered())
+        q.put(flat.gathered().numpy())       # numpy: pickled through the pipe (a torch tensor travels as a shared-
+                                             # memory handle that dies with this process)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -106,7 +107,7 @@ def test_two_rank_gradient_allreduce_equals_two_replica_emulation():
     procs = [ctx.Process(target=_dp_worker, args=(r, world, port, batch, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=300)
+    got = torch.from_numpy(q.get(timeout=300))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -140,7 +141,7 @@ def _bucket_worker(rank, world, port, q):
         net(x).pow(2).sum().backward()
         fired_early = sum(flat._launched) + len(flat._direct_done)
         flat.finish()
-        res.append((flat.gathered(), fired_early))
+        res.append((flat.gathered().numpy().copy(), fired_early))   # numpy: see _dp_worker
     if rank == 0:
         q.put(res)
     dist.barrier()
@@ -162,6 +163,7 @@ def test_bucketed_overlapped_allreduce_two_ranks():
         p.join(60)
         assert p.exitcode == 0
     for it, (got, fired_early) in enumerate(res):
+        got = torch.from_numpy(got)
         assert fired_early >= 2                            # overlap: launched from the hooks
         want = None
         for r in range(world):
