@@ -80,7 +80,7 @@ int vg_internal_ring_conv(int mode, const float* x, const void* packed, const fl
                           const float* in_shift, int in_act, float* stats, size_t stats_floats, hipStream_t st);
 #ifdef VG_TUNING
 void vg_internal_ring_set_variant(int v);
-void vg_internal_wx_set_rounds(int r);
+void vg_internal_wx_set_th(int th);
 #endif
 int vg_internal_convT_s1_thin(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H,
                               int W, int Cout, hipStream_t st);

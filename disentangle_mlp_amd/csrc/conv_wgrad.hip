@@ -343,7 +343,7 @@ extern "C" int vg_debug_set_wgrad(int what, int value) {
   else if (what == 2) g_wgrad_ks = value;
   else if (what == 3) g_wgrad_cit = value;
   else if (what == 4) g_wgrad_vec4 = value;
-  else if (what == 5) vg_internal_wx_set_rounds(value);     // split-bf16 kernel: workgroups per CU its K split aims at
+  else if (what == 5) vg_internal_wx_set_th(value);         // split-bf16 kernel: pixel rows of a chunk (1 / 2; 0 = planned)
   else return VG_ERR_BAD_ARG;
   return 0;
 }

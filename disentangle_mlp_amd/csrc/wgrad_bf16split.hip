@@ -21,6 +21,9 @@
 //   * the gy operand goes global -> register (32 consecutive co = 512 contiguous bytes), prefetched
 //     one pixel ahead -- no LDS, no barrier for it;
 //   * split-K over chunks, partial slabs summed in a fixed order by conv_wgrad.hip's reduction.
+#include <algorithm>
+#include <vector>
+
 #include "common.hpp"
 #include "vaegan_hip.h"
 
@@ -40,8 +43,9 @@ struct WXArgs {
   const bf16x8* gp;
   float* ws;
   int Cin, H, W, Cout, CoP, OH, OW;
-  int mtiles, ntiles, splits, tiles_w, tiles_hw, chunks, chunks_per_split;
-  int xcd_aware;
+  int mtiles, ntiles, tiles_w, tiles_hw, chunks;
+  int units, upw;                 // units = output tiles x chunks; every workgroup works off upw consecutive ones
+  unsigned short order[256];      // launch slot (blockIdx.x) -> workgroup index
 };
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
@@ -113,26 +117,40 @@ __global__ __launch_bounds__(256) void relayout_gy_kernel(const float* __restric
 // ---- the weight-gradient kernel: one workgroup of 8 wavefronts per CU ------------------------------------------
 // Output tile = TCO cout x 5 input channels (125 of 128 columns); WCO wavefronts along cout (32 rows each, so every
 // wavefront streams ONLY its own gy rows, global -> register, prefetched PD pixels ahead) x WN = 8 / WCO column
-// groups of 128 / WN columns.  A chunk = 16 images x (1 x 8) output pixels: its x patch [plane][k-block][5 ci]
-// [5 rows][S*7+5 cols] (50 KB for 3 planes) is double-buffered in LDS -- the next chunk's units are loaded into
-// registers at the first pixel of a chunk and written at its sixth, ONE barrier per chunk -- so the MFMAs never
-// wait for a copy.  (The 4-wavefront predecessor staged the patch between two barriers and prefetched gy one
-// pixel ahead: 142 TFLOP/s on 128 -> 256 @32 -> 16.)  Plain loads only: hipcc counts them (vmcnt) itself.
+// groups of 128 / WN columns.  A chunk = 16 images x (TH x 8) output pixels, TH = 2 when the output height is even:
+// its x patch [plane][k-block][5 ci][S*(TH-1)+5 rows][S*7+5 cols] (72 KB for 3 planes at TH = 2) is double-buffered in
+// LDS -- the next chunk's units are loaded into registers at the first pixel of a chunk and split + written one unit
+// at a time at later pixels (the two wavefronts of a SIMD at different ones), ONE barrier per chunk -- so the MFMAs
+// never wait for a copy.  Work is dealt out in equal shares of (tile, chunk) units (plan_shares below).  (The
+// 4-wavefront predecessor staged the patch between two barriers and prefetched gy one pixel ahead: 142 TFLOP/s on
+// 128 -> 256 @32 -> 16.)  Plain loads only: hipcc counts them (vmcnt) itself.
 constexpr int W8NT = 512;
+// timing experiments only (experiments/abl_build.sh): 1 gy always from pixel 0 (cache-resident), 2 x patch loaded once,
+// 4 patch split + LDS store once, 8 no MFMAs, 16 patch fragments read once
+#ifndef VG_WX_ABL
+#define VG_WX_ABL 0
+#endif
 
-template <int S_, int NP_, int WCO_>
+template <int S_, int NP_, int WCO_, int TH_>
 struct W8 {
   static constexpr int S = S_, NP = NP_, WCO = WCO_, WN = 8 / WCO_, FP = 4 / WN, TCO = 32 * WCO_;
+  static constexpr int TH = TH_, NPIX = TH_ * WTW;                                // output pixels of a chunk: TH rows x 8
   // gy prefetch distance in pixels (register sets - 1): a pixel step is FP * 6 (or 3) MFMAs per wavefront, i.e. 0.35 /
   // 0.7 us, against ~2 us for a first touch of gy from HBM; the 2-fragment tile has the registers for 8 sets
   static constexpr int PD = (FP <= 2) ? 7 : 3;
-  static constexpr int PH = 5, PW = S * (WTW - 1) + 5;
+  static constexpr int PH = S * (TH - 1) + 5, PW = S * (WTW - 1) + 5;
   static constexpr int ROWU = PW + ((5 - PW % 16) + 16) % 16;                    // = 5 (mod 16)
   static constexpr int CIU = PH * ROWU + ((9 - (PH * ROWU) % 16) + 16) % 16;     // = 9 (mod 16)
   static constexpr int KBU = WCIT * CIU;                                          // units per (plane, k-block)
   static constexpr int BUFU = 2 * NP * KBU;                                       // units per patch buffer
   static constexpr int NUNIT = 2 * WCIT * PH * PW;          // staged units (k-block, ci, row, col): 8 images each
   static constexpr int NQ = cdiv(NUNIT, W8NT);
+  // the patch of chunk + 1 is loaded at pixel 0 and written to the other buffer one unit per thread at a time, the
+  // two wavefronts of a SIMD (w, w + 4) at different pixels, so that one's split arithmetic runs under the other's
+  // MFMAs: wavefronts 0-3 at pixels ST0 + q * STEP, wavefronts 4-7 NQ * STEP later
+  static constexpr int STEP = TH, ST0 = NPIX / 4;
+  static_assert(ST0 + 2 * NQ * STEP <= NPIX, "store schedule");
+  static_assert(NPIX % (PD + 1) == 0, "gy ring");
   static_assert(2 * BUFU * 16 <= 160 * 1024, "LDS");
 };
 
@@ -145,26 +163,19 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kb = lane >> 5, l32 = lane & 31;
   const int wm = wid % C::WCO, wn = wid / C::WCO;
-  // XCD-aware placement: all output tiles of one K split read the same gy / x chunks -> one XCD (speed only)
-  int bid = blockIdx.x;
-  {
-    const int T = A.mtiles * A.ntiles, full = (A.splits / 8) * 8 * T;
-    if (bid < full && A.xcd_aware) {
-      const int xcd = bid & 7, slot = bid >> 3;
-      bid = ((slot / T) * 8 + xcd) * T + slot % T;
-    }
-  }
-  const int mt = bid % A.mtiles;
-  bid /= A.mtiles;
-  const int nt = bid % A.ntiles, split = bid / A.ntiles;
-  const int m0 = mt * C::TCO, ci0 = nt * WCIT;
+  const int grp = wid >> 2;                  // which of the two wavefronts of its SIMD
+  // This workgroup's share of the work: units [u_begin, u_end) of the (output tile, chunk) space, tile-major -- every
+  // workgroup gets the same number of chunks whatever the tile count (a share that crosses a tile boundary is worked
+  // off as two segments).  A.order places workgroups with neighbouring chunk ranges on one XCD (speed only).
+  const int wg = A.order[blockIdx.x];
+  const int u_begin = wg * A.upw, u_end = min(u_begin + A.upw, A.units);
   const int Cin = A.Cin, Cout = A.Cout, H = A.H, W = A.W, OW = A.OW, CoP = A.CoP;
   const int HW = H * W, P = A.OH * A.OW;
+  int m0 = 0, ci0 = 0;                       // the current segment's output tile
 
   // ---- staging map: unit e = (k-block, ci, row, col) = 8 images of one input pixel, read straight from x (NCHW
   // fp32: 8 loads a channel-image apart), split into the NP planes in registers and written as NP 16-byte LDS units.
-  // One packed descriptor per unit: row | col << 4 | ci << 9 | kb << 12 | state << 13 (state 0 = no unit, 1 = copy,
-  // 2 = channel beyond Cin -> zeros).
+  // One packed descriptor per unit: row | col << 4 | ci << 9 | kb << 12 | present << 13.
   int desc[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
@@ -174,8 +185,7 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
     const int r = t % PH;
     t /= PH;
     const int ci = t % WCIT, kbs = min(t / WCIT, 1);
-    const int state = e < C::NUNIT ? ((ci0 + ci) < Cin ? 1 : 2) : 0;
-    desc[q] = r | (col << 4) | (ci << 9) | (kbs << 12) | (state << 13);
+    desc[q] = r | (col << 4) | (ci << 9) | (kbs << 12) | ((e < C::NUNIT ? 1 : 0) << 13);
   }
   static_assert(PH <= 16 && PW <= 32 && WCIT <= 8, "descriptor fields");
 
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
   auto chunk_pos = [&](int chunk, int& bg, int& oh, int& ow0) {
     bg = chunk / A.tiles_hw;
     const int sp = chunk % A.tiles_hw;
-    oh = sp / A.tiles_w;
+    oh = (sp / A.tiles_w) * C::TH;
     ow0 = (sp % A.tiles_w) * WTW;
   };
   float preg[NQ][8], psc[NQ], psh[NQ];
@@ -199,7 +209,7 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
       const int d = desc[q];
       const int ih = ih0 + (d & 15), iw = iw0 + ((d >> 4) & 31);
       const int ci = (d >> 9) & 7, kbs = (d >> 12) & 1;
-      const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
+      const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W && (ci0 + ci) < Cin;   // channels past Cin: zeros
       pvalid |= ok ? (1u << q) : 0u;
       const int cc = min(ci0 + ci, Cin - 1);
       const unsigned off = (unsigned)(cc * HW + min(max(ih, 0), H - 1) * W + min(max(iw, 0), W - 1));
@@ -213,32 +223,33 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
       }
     }
   };
-  auto store_patch = [&](int buf, int chunk) {
+  auto store_unit = [&](int q, int buf, int chunk) {
     const int bgrp = chunk / A.tiles_hw;
+    const int d = desc[q];
+    const int kbs = (d >> 12) & 1;
+    const bool live = (pvalid >> q) & 1u;
+    float v[8];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int d = desc[q];
-      const int state = d >> 13, kbs = (d >> 12) & 1;
-      const bool live = state == 1 && ((pvalid >> q) & 1u);
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float t = fmaf(preg[q][j], psc[q], psh[q]);                    // the producing layer's BatchNorm ...
-        t = fmaxf(t, 0.f) + A.in_slope * fminf(t, 0.f);                // ... and activation, on load
-        v[j] = (live && (bgrp * 16 + kbs * 8 + j) < A.B) ? t : 0.f;    // padding pads the activated tensor
-      }
-      bf16x8 pl[NP];
-      split_planes<NP>(v, pl);
-      const int dst = buf * BUFU + kbs * KBU + ((d >> 9) & 7) * CIU + (d & 15) * ROWU + ((d >> 4) & 31);
-      if (state != 0) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) lds[dst + p * 2 * KBU] = __builtin_bit_cast(f32x4, pl[p]);
-      }
+    for (int j = 0; j < 8; ++j) {
+      float t = fmaf(preg[q][j], psc[q], psh[q]);                    // the producing layer's BatchNorm ...
+      t = fmaxf(t, 0.f) + A.in_slope * fminf(t, 0.f);                // ... and activation, on load
+      v[j] = (live && (bgrp * 16 + kbs * 8 + j) < A.B) ? t : 0.f;    // padding pads the activated tensor
     }
+    bf16x8 pl[NP];
+    split_planes<NP>(v, pl);
+    const int dst = buf * BUFU + kbs * KBU + ((d >> 9) & 7) * CIU + (d & 15) * ROWU + ((d >> 4) & 31);
+    if (d >> 13) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) lds[dst + p * 2 * KBU] = __builtin_bit_cast(f32x4, pl[p]);
+    }
+  };
+  auto store_patch = [&](int buf, int chunk) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) store_unit(q, buf, chunk);
   };
   static_assert(NQ <= 32, "validity mask");
 
-  // ---- per-lane operand bases
+  // ---- per-lane base of the patch operand
   int base_b[FP];
 #pragma unroll
   for (int f = 0; f < FP; ++f) {
@@ -246,85 +257,131 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
     const int ci = n / 25, tap = n % 25;
     base_b[f] = kb * KBU + ci * CIU + (tap / 5) * ROWU + tap % 5;
   }
-  const bf16x8* ga = A.gp + (size_t)kb * CoP + m0 + wm * 32 + l32;     // this lane's cout row, k-block
-  const size_t gstep = (size_t)2 * NP * CoP;                           // units per pixel
+  const size_t gstep = (size_t)2 * NP * CoP;                           // gy units per pixel
+  auto pix_off = [&](int k) -> size_t { return (size_t)(k >> 3) * OW + (k & 7); };   // pixel k of a chunk
 
-  f32x16 acc[FP];
-#pragma unroll
-  for (int f = 0; f < FP; ++f)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+  for (int u = u_begin; u < u_end;) {
+    // ---- one segment: chunks [c_begin, c_end) of one output tile
+    const int tile = u / A.chunks, c_begin = u - tile * A.chunks;
+    const int c_end = min(A.chunks, c_begin + (u_end - u));
+    u += c_end - c_begin;
+    m0 = (tile % A.mtiles) * C::TCO;
+    ci0 = (tile / A.mtiles) * WCIT;
+    const bf16x8* ga = A.gp + (size_t)kb * CoP + m0 + wm * 32 + l32;   // this lane's cout row, k-block
 
-  const int c_begin = split * A.chunks_per_split;
-  const int c_end = min(c_begin + A.chunks_per_split, A.chunks);
-  if (c_begin < c_end) {
-    // first pixel (in Gp) of a chunk, clamped to the last chunk of this split (prefetches past the end are unused)
+    f32x16 acc[FP];
+#pragma unroll
+    for (int f = 0; f < FP; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    // first pixel (in Gp) of a chunk, clamped to the last chunk of the segment (prefetches past the end are unused)
     auto chunk_pix = [&](int chunk) -> size_t {
       int bg, oh, ow0;
       chunk_pos(min(chunk, c_end - 1), bg, oh, ow0);
       return (size_t)bg * P + (size_t)oh * OW + ow0;
     };
-    bf16x8 av[PD + 1][NP];      // gy fragments of pixels t .. t+PD, ring indexed by (pixel & PD) (PD + 1 = 4 sets)
-    static_assert((PD == 3 || PD == 7) && WTW == 8, "ring indices below assume 4 or 8 sets, 8 pixels per chunk");
+    bf16x8 av[PD + 1][NP];      // gy fragments of pixels t .. t+PD, ring indexed by (pixel & PD) (PD + 1 = 4 or 8 sets)
+    static_assert((PD == 3 || PD == 7) && WTW == 8, "ring indices below assume 4 or 8 sets, 8 pixels per row");
     auto load_a = [&](int set, size_t pix) {
 #pragma unroll
-      for (int pl = 0; pl < NP; ++pl) av[set][pl] = ga[pix * gstep + (size_t)pl * 2 * CoP];
+      for (int pl = 0; pl < NP; ++pl) av[set][pl] = ga[((VG_WX_ABL & 1) ? 0 : pix) * gstep + (size_t)pl * 2 * CoP];
     };
     load_patch(c_begin);
     store_patch(0, c_begin);
     size_t pcur = chunk_pix(c_begin);
 #pragma unroll
-    for (int t = 0; t < PD; ++t) load_a(t, pcur + t);
+    for (int t = 0; t < PD; ++t) load_a(t, pcur + pix_off(t));
     __syncthreads();
     for (int ch = c_begin; ch < c_end; ++ch) {
       const int buf = (ch - c_begin) & 1;
       const bool more = (ch + 1) < c_end;
       const size_t pnxt = chunk_pix(ch + 1);
 #pragma unroll
-      for (int t = 0; t < WTW; ++t) {
+      for (int t = 0; t < C::NPIX; ++t) {
         // gy fragments PD pixels ahead (the last PD pixels of a chunk fetch the first ones of the next chunk)
-        load_a((t + PD) & PD, (t + PD < WTW) ? pcur + t + PD : pnxt + (t + PD - WTW));     // PD = 7: always the next chunk
-        if (t == 0 && more) load_patch(ch + 1);
+        load_a((t + PD) & PD, (t + PD < C::NPIX) ? pcur + pix_off(t + PD) : pnxt + pix_off(t + PD - C::NPIX));
+        if (t == 0 && more && !(VG_WX_ABL & 2)) load_patch(ch + 1);
         bf16x8 bv[FP][NP];
+        if (!(VG_WX_ABL & 16) || (ch == c_begin && t == 0)) {
 #pragma unroll
-        for (int f = 0; f < FP; ++f)
+          for (int f = 0; f < FP; ++f)
 #pragma unroll
-          for (int pl = 0; pl < NP; ++pl)
-            bv[f][pl] = __builtin_bit_cast(bf16x8, lds[buf * BUFU + base_b[f] + S * t + pl * 2 * KBU]);
+            for (int pl = 0; pl < NP; ++pl)
+              bv[f][pl] = __builtin_bit_cast(
+                  bf16x8, lds[buf * BUFU + base_b[f] + S * (t >> 3) * ROWU + S * (t & 7) + pl * 2 * KBU]);
+        }
         // products with plane index sum < NP, smallest terms first, product-major
 #pragma unroll
         for (int sum = NP - 1; sum >= 0; --sum)
 #pragma unroll
           for (int pa = sum; pa >= 0; --pa)
 #pragma unroll
-            for (int f = 0; f < FP; ++f) acc[f] = mfma_bf16(av[t & PD][pa], bv[f][sum - pa], acc[f]);
-        if (t == 5 && more) store_patch(buf ^ 1, ch + 1);      // the other buffer was last read in the previous chunk
+            for (int f = 0; f < FP; ++f) {
+              if (!(VG_WX_ABL & 8)) acc[f] = mfma_bf16(av[t & PD][pa], bv[f][sum - pa], acc[f]);
+              else acc[f][0] += (float)av[t & PD][pa][0] + (float)bv[f][sum - pa][0];
+            }
+        // one unit of the next patch per slot of the store schedule (the other buffer was last read a chunk ago)
+        {
+          const int rel = t - C::ST0;
+          if (rel >= 0 && rel % C::STEP == 0 && rel / C::STEP < 2 * NQ) {
+            const int q = (rel / C::STEP) % NQ, g = (rel / C::STEP) / NQ;
+            if (more && grp == g && !(VG_WX_ABL & 4)) store_unit(q, buf ^ 1, ch + 1);
+          }
+        }
       }
-      __syncthreads();
+      __syncthreads();                                   // also frees both patch buffers for the next segment
       pcur = pnxt;
     }
-  }
 
-  // ---- partial slab: ws[split][co][ci*25 + tap]
-  float* wsb = A.ws + (size_t)split * Cout * Cin * 25;
+    // ---- this segment's partial slab: ws[piece][co][ci*25 + tap], piece = position among the tile's workgroups
+    const int piece = wg - (int)(((long)tile * A.chunks) / A.upw);
+    float* wsb = A.ws + (size_t)piece * Cout * Cin * 25;
 #pragma unroll
-  for (int f = 0; f < FP; ++f) {
-    const int n = (wn * FP + f) * 32 + l32;
-    const bool nok = n < WCIT * 25 && (ci0 + n / 25) < Cin;
+    for (int f = 0; f < FP; ++f) {
+      const int n = (wn * FP + f) * 32 + l32;
+      const bool nok = n < WCIT * 25 && (ci0 + n / 25) < Cin;
 #pragma unroll
-    for (int r16 = 0; r16 < 16; ++r16) {
-      const int co = m0 + wm * 32 + acc_row(r16, lane);
-      if (nok && co < Cout) wsb[((size_t)co * Cin + ci0) * 25 + n] = acc[f][r16];
+      for (int r16 = 0; r16 < 16; ++r16) {
+        const int co = m0 + wm * 32 + acc_row(r16, lane);
+        if (nok && co < Cout) wsb[((size_t)co * Cin + ci0) * 25 + n] = acc[f][r16];
+      }
     }
   }
 }
 
+// dw[e] = sum of the pieces of e's output tile, in workgroup order (fixed: the result does not depend on timing)
+__global__ __launch_bounds__(256) void wx_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int Cin,
+                                                       int tco, int mtiles, int chunks, int upw, unsigned n) {
+  const unsigned e = blockIdx.x * 256u + threadIdx.x;
+  if (e >= n) return;
+  const int row = Cin * 25, co = e / row, ci = (e - co * row) / 25;
+  const long tile = (long)(ci / WCIT) * mtiles + co / tco;
+  const int first = (int)((tile * chunks) / upw), last = (int)(((tile + 1) * chunks - 1) / upw);
+  float sum = 0.f;
+  for (int p = 0; p <= last - first; ++p) sum += slabs[(size_t)p * n + e];
+  dw[e] = sum;
+}
+
 struct XPlan {
-  int BG, CoP, OH, OW, wco, mtiles, ntiles, tiles_w, tiles_hw, chunks, cps, splits;
+  int BG, CoP, OH, OW, wco, th, mtiles, ntiles, tiles_w, tiles_hw, chunks, units, upw, wgs, pieces;
   size_t gp_bytes, slab_bytes;
 };
 
-VG_KNOB(int, g_wx_rounds, 1);     // tuning build: workgroups per CU the K split aims at
+VG_KNOB(int, g_wx_th, 0);     // tuning build: force the pixel rows of a chunk (0: chosen by the plan)
+
+// Work split: units = output tiles x chunks, tile-major, dealt out in equal consecutive shares to at most one
+// workgroup per CU -- the tile count (26 for Cin = 128) rarely divides 256, and whole K splits per tile left 9-19 % of
+// the CUs idle on the benchmark's layers.  A tile's partial results ("pieces", one per workgroup that touched it) are
+// summed in workgroup order by wx_reduce_kernel.
+void plan_shares(XPlan& p, int th) {
+  p.th = th;
+  p.tiles_hw = p.tiles_w * (p.OH / th);
+  p.chunks = p.BG * p.tiles_hw;
+  p.units = p.mtiles * p.ntiles * p.chunks;
+  p.upw = cdiv(p.units, 256);
+  p.wgs = cdiv(p.units, p.upw);
+}
 
 bool make_xplan(int B, int Cin, int H, int W, int Cout, int S, int planes, XPlan& p) {
   p.OH = (H - 1) / S + 1;
@@ -336,19 +393,33 @@ bool make_xplan(int B, int Cin, int H, int W, int Cout, int S, int planes, XPlan
   p.mtiles = cdiv(Cout, 32 * p.wco);
   p.ntiles = cdiv(Cin, WCIT);
   p.tiles_w = p.OW / WTW;
-  p.tiles_hw = p.tiles_w * p.OH;
-  p.chunks = p.BG * p.tiles_hw;
-  // K split: one workgroup per CU and (just under) one round of them -- every workgroup does the same work, and
-  // each extra split is one more slab (Cout x Cin x 25 floats) to write and sum
-  const int tiles = p.mtiles * p.ntiles;
-  int want = (256 * g_wx_rounds) / tiles;
-  if (want > p.chunks) want = p.chunks;
-  if (want < 1) want = 1;
-  p.cps = cdiv(p.chunks, want);
-  p.splits = cdiv(p.chunks, p.cps);
+  if ((long)p.mtiles * p.ntiles * p.BG * p.tiles_w * p.OH > 0x3fffffffL) return false;
+  // chunk = 16 images x (th x 8) output pixels: two rows whenever the output height allows it (half the barriers,
+  // 30 % fewer staged patch units per pixel; measured 2-4 % faster than one row even where one row deals the finer,
+  // better balanced shares)
+  int th = (p.OH % 2 == 0) ? 2 : 1;
+  if (g_wx_th == 1 || (g_wx_th == 2 && p.OH % 2 == 0)) th = g_wx_th;
+  plan_shares(p, th);
+  p.pieces = 0;
+  for (long t = 0; t < (long)p.mtiles * p.ntiles; ++t) {
+    const int first = (int)((t * p.chunks) / p.upw), last = (int)(((t + 1) * p.chunks - 1) / p.upw);
+    p.pieces = last - first + 1 > p.pieces ? last - first + 1 : p.pieces;
+  }
   p.gp_bytes = (size_t)p.BG * p.OH * p.OW * 2 * planes * p.CoP * 16;
-  p.slab_bytes = (size_t)p.splits * Cout * Cin * 25 * sizeof(float);
+  p.slab_bytes = (size_t)p.pieces * Cout * Cin * 25 * sizeof(float);
   return true;
+}
+
+// launch slot -> workgroup: workgroups sorted by where their share starts inside a tile (they read the same gy / x
+// chunks as their neighbours in that order), dealt to the XCDs in runs (slot b runs on XCD b % 8)
+void make_order(const XPlan& p, unsigned short* order) {
+  std::vector<int> idx(p.wgs);
+  for (int w = 0; w < p.wgs; ++w) idx[w] = w;
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+    return ((long)a * p.upw) % p.chunks < ((long)b * p.upw) % p.chunks;
+  });
+  for (int b = 0; b < p.wgs; ++b)
+    order[b] = (unsigned short)((p.wgs % 8 == 0) ? idx[(b & 7) * (p.wgs / 8) + (b >> 3)] : b);
 }
 
 template <class C>
@@ -359,14 +430,15 @@ int launch_wx(const WXArgs& A, long grid, hipStream_t st) {
 }
 
 template <int S, int NP>
-int launch_wx_by_cout(const WXArgs& A, int wco, long grid, hipStream_t st) {
-  return wco == 8 ? launch_wx<W8<S, NP, 8>>(A, grid, st) : launch_wx<W8<S, NP, 4>>(A, grid, st);
+int launch_wx_by_cout(const WXArgs& A, int wco, int th, long grid, hipStream_t st) {
+  if (th == 2) return wco == 8 ? launch_wx<W8<S, NP, 8, 2>>(A, grid, st) : launch_wx<W8<S, NP, 4, 2>>(A, grid, st);
+  return wco == 8 ? launch_wx<W8<S, NP, 8, 1>>(A, grid, st) : launch_wx<W8<S, NP, 4, 1>>(A, grid, st);
 }
 
 }  // namespace
 
 #ifdef VG_TUNING
-void vg_internal_wx_set_rounds(int r) { g_wx_rounds = r > 0 ? r : 1; }
+void vg_internal_wx_set_th(int th) { g_wx_th = (th == 1 || th == 2) ? th : 0; }
 #endif
 
 extern "C" size_t vg_conv5x5_wgrad_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride,
@@ -407,14 +479,17 @@ extern "C" int vg_conv5x5_wgrad_bf16split(const float* x, const float* gy, float
   A.in_scale = in_scale; A.in_shift = in_shift;
   A.in_slope = in_scale ? slope : 1.f;
   A.Cin = Cin; A.H = H; A.W = W; A.Cout = Cout; A.CoP = p.CoP; A.OH = p.OH; A.OW = p.OW;
-  A.mtiles = p.mtiles; A.ntiles = p.ntiles; A.splits = p.splits; A.tiles_w = p.tiles_w; A.tiles_hw = p.tiles_hw;
-  A.chunks = p.chunks; A.chunks_per_split = p.cps;
-  A.xcd_aware = 1;
-  const long grid = (long)p.mtiles * p.ntiles * p.splits;
-  if (grid > 0x7fffffffL) return VG_ERR_BAD_ARG;
+  A.mtiles = p.mtiles; A.ntiles = p.ntiles; A.tiles_w = p.tiles_w; A.tiles_hw = p.tiles_hw;
+  A.chunks = p.chunks; A.units = p.units; A.upw = p.upw;
+  make_order(p, A.order);
+  const long grid = p.wgs;
   int rc;
-  if (planes == 2) rc = (stride == 2) ? launch_wx_by_cout<2, 2>(A, p.wco, grid, st) : launch_wx_by_cout<1, 2>(A, p.wco, grid, st);
-  else rc = (stride == 2) ? launch_wx_by_cout<2, 3>(A, p.wco, grid, st) : launch_wx_by_cout<1, 3>(A, p.wco, grid, st);
+  if (planes == 2) rc = (stride == 2) ? launch_wx_by_cout<2, 2>(A, p.wco, p.th, grid, st) : launch_wx_by_cout<1, 2>(A, p.wco, p.th, grid, st);
+  else rc = (stride == 2) ? launch_wx_by_cout<2, 3>(A, p.wco, p.th, grid, st) : launch_wx_by_cout<1, 3>(A, p.wco, p.th, grid, st);
   if (rc) return rc;
-  return vg_internal_wgrad_reduce(slabs, dw, Cout * Cin * 25, p.splits, st);
+  const unsigned n = (unsigned)Cout * Cin * 25;
+  hipLaunchKernelGGL(wx_reduce_kernel, dim3(cdiv(n, 256u)), dim3(256), 0, st, slabs, dw, Cin, 32 * p.wco, p.mtiles,
+                     p.chunks, p.upw, n);
+  VG_CHECK_LAUNCH();
+  return 0;
 }

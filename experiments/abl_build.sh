@@ -1,13 +1,22 @@
 #!/bin/bash
-# One-off libraries of the ring kernel with pieces of its K step compiled out (conv_ring.hip, VG_RING_ABL bits):
-# timing experiments only -- results are wrong by construction.  Output: experiments/abl/libabl_<bits>.so
+# One-off libraries of a kernel file with pieces of its inner loop compiled out (timing experiments only -- results are
+# wrong by construction):  abl_build.sh <ring|wx> <bits> ...   ->  experiments/abl/libabl_<which>_<bits>.so
+#   ring: conv_ring.hip,       -DVG_RING_ABL=<bits>
+#   wx:   wgrad_bf16split.hip, -DVG_WX_ABL=<bits>
 set -e
 cd "$(dirname "$0")/.."
 C=disentangle_mlp_amd/csrc
-OBJS=$(ls $C/build/*.o | grep -v conv_ring.o)
+which=$1; shift
+case $which in
+  ring) SRC=conv_ring; DEF=VG_RING_ABL ;;
+  wx)   SRC=wgrad_bf16split; DEF=VG_WX_ABL ;;
+  *) echo "usage: $0 <ring|wx> <bits> ..."; exit 2 ;;
+esac
+mkdir -p experiments/abl
+OBJS=$(ls $C/build/*.o | grep -v "/$SRC.o")
 for bits in "$@"; do
-  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -I$C -Wno-unused-result -mllvm -pragma-unroll-threshold=131072 -DVG_RING_ABL=$bits -c $C/conv_ring.hip -o experiments/abl/ring_$bits.o &&
-    /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o experiments/abl/libabl_$bits.so experiments/abl/ring_$bits.o $OBJS ) &
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -I$C -Wno-unused-result -mllvm -pragma-unroll-threshold=131072 -D$DEF=$bits -c $C/$SRC.hip -o experiments/abl/${which}_$bits.o &&
+    /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o experiments/abl/libabl_${which}_$bits.so experiments/abl/${which}_$bits.o $OBJS ) &
 done
 wait
 ls -la experiments/abl/*.so

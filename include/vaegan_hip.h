@@ -296,7 +296,7 @@ int vg_debug_set_conv_tile(int mode, int variant);
 /* Diagnostics / tuning only: what=0 caps the wgrad cout tile (32/64/128, -1 = heuristic);
  * what=1 sets the split-K workgroup target (-1 = heuristic); what=2 the K groups of the 128-row
  * tile (1 or 2); what=3 the input channels per column tile (5 or 10); what=4: 0 = scalar gy loads;
- * what=5: workgroups per CU the K split of vg_conv5x5_wgrad_bf16split aims at (default 1). */
+ * what=5: output-pixel rows per chunk of vg_conv5x5_wgrad_bf16split (1 or 2; 0 = chosen by its plan). */
 int vg_debug_set_wgrad(int what, int value);
 /* split-bf16 kernels of conv_bf16split.hip: 0 = 128x128, 1 = 64x128, 2 = 64x64, 3 = 32x128, 4 = 32x256 (transposed),
  * 5 = 128x128 with the 4 wavefronts along cout, -1 = heuristic */

@@ -12,12 +12,12 @@ sys.path.insert(0, ROOT)
 import torch
 from disentangle_mlp_amd import _lib
 if bits:
-    _lib.LIB_PATH = os.path.join(ROOT, "experiments", "abl", f"libabl_{bits}.so")
+    _lib.LIB_PATH = os.path.join(ROOT, "experiments", "abl", f"libabl_ring_{bits}.so")
 from disentangle_mlp_amd import ops
 ops.CONV_ARITH = "bf16x6"
 B = 128
 def timeit(fn, n=15):
-    for _ in range(3): fn()
+    for _ in range(60): fn()          # the clock takes tens of launches to settle after idle
     torch.cuda.synchronize()
     ts = []
     for _ in range(n):

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from disentangle_mlp_amd import ops
 def timeit(fn, n=20):
-    for _ in range(3): fn()
+    for _ in range(60): fn()          # the clock takes tens of launches to settle after idle
     torch.cuda.synchronize()
     ts = []
     for _ in range(n):

@@ -11,7 +11,7 @@ FWD = [(32, 128, 64), (64, 128, 32), (128, 256, 32), (128, 256, 16), (256, 256, 
 TR = [(256, 256, 8), (256, 128, 16), (256, 128, 8), (128, 64, 16), (128, 32, 32)]
 peak = 2500.0 / (6 if ops.CONV_ARITH == "bf16x6" else 3)
 def timeit(fn, n=20):
-    for _ in range(3): fn()
+    for _ in range(60): fn()          # the clock takes tens of launches to settle after idle
     torch.cuda.synchronize()
     ts = []
     for _ in range(n):
