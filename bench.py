@@ -227,6 +227,7 @@ def main():
         for i in range(n):
             o = one_step()
             marks[i + 1].record()
+        timed_steps.host_ms = (time.perf_counter() - t0) * 1e3 / n      # host time to ENQUEUE a step (no waiting)
         fence()
         wall = time.perf_counter() - t0
         return wall, [marks[i].elapsed_time(marks[i + 1]) for i in range(n)], o
@@ -244,6 +245,7 @@ def main():
     # ---- timed region: exactly K steps, dominant kernel bracketed by HIP events
     ops.start_timing(only=dominant)
     elapsed, step_ms, out = timed_steps(args.steps)
+    host_ms = timed_steps.host_ms
     dom_ms = ops.stop_timing().get(dominant, [])
 
     # ---- informational: the same K steps in the other arithmetics (N = 1 only; NOT `value`)
@@ -305,6 +307,7 @@ def main():
             "metric": "celeba64_betavaegan_train_images_per_sec", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "ms_per_step_median": round(statistics.median(step_ms), 3),
+            "host_enqueue_ms_per_step": round(host_ms, 3),     # Python + launch calls only: below ms_per_step = GPU-bound
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32" if arith == "fp32" else
                      "fp32-equivalent (%s split of fp32 operands on the bf16 MFMA, fp32 accumulate; 3-channel layers and "

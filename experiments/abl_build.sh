@@ -3,6 +3,7 @@
 # wrong by construction):  abl_build.sh <ring|wx> <bits> ...   ->  experiments/abl/libabl_<which>_<bits>.so
 #   ring: conv_ring.hip,       -DVG_RING_ABL=<bits>
 #   wx:   wgrad_bf16split.hip, -DVG_WX_ABL=<bits>
+#   gemm: gemm_split.hip,      -DVG_GEMM_ABL=<bits>
 set -e
 cd "$(dirname "$0")/.."
 C=disentangle_mlp_amd/csrc
@@ -10,7 +11,8 @@ which=$1; shift
 case $which in
   ring) SRC=conv_ring; DEF=VG_RING_ABL ;;
   wx)   SRC=wgrad_bf16split; DEF=VG_WX_ABL ;;
-  *) echo "usage: $0 <ring|wx> <bits> ..."; exit 2 ;;
+  gemm) SRC=gemm_split; DEF=VG_GEMM_ABL ;;
+  *) echo "usage: $0 <ring|wx|gemm> <bits> ..."; exit 2 ;;
 esac
 mkdir -p experiments/abl
 OBJS=$(ls $C/build/*.o | grep -v "/$SRC.o")
