@@ -117,6 +117,9 @@ if CONV_ARITH not in ("fp32", "bf16x3", "bf16x6"):
     raise ImportError(f"VG_CONV_ARITH={CONV_ARITH!r}: expected 'fp32', 'bf16x3' or 'bf16x6'")
 
 
+THIN_SPLIT = os.environ.get("VG_THIN_SPLIT", "1") != "0"   # 0: the 3-channel edge layers stay on the fp32 VALU / fp32-MFMA kernels in every arithmetic
+
+
 def _planes():
     """bf16 operand planes of the active arithmetic: 0 (exact fp32 MFMA), 2 (bf16x3) or 3 (bf16x6)."""
     return {"fp32": 0, "bf16x3": 2, "bf16x6": 3}[CONV_ARITH]
@@ -320,6 +323,16 @@ def convT5x5_fwd(x, w, bias, stride, in_affine=None, want_stats=False):
                                              __import__("ctypes").byref(f) if f is not None else None, _stream()),
                   "vg_convT5x5_fwd_bf16split")
         return (y, stats) if want_stats else y
+    if thin and _planes() and THIN_SPLIT and lib.vg_convT5x5_s1_thin_bf16split_ok(Cin, H, W, Cout):
+        # 32 -> (<= 3) channels: filter resident in registers, one pass over x (BatchNorm + activation applied on load)
+        scale, shift, act = in_affine if in_affine is not None else (None, None, ACT_NONE)
+        if scale is not None:
+            _req(scale, "in_scale"), _req(shift, "in_shift")
+        with _timed(("convT_fwd", B, Cin, H, W, Cout, stride)):
+            check(lib.vg_convT5x5_s1_thin_bf16split(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W, Cout,
+                                                    _planes(), _ptr(scale), _ptr(shift), int(act), _stream()),
+                  "vg_convT5x5_s1_thin_bf16split")
+        return (y, None) if want_stats else y
     x = _materialize(x, in_affine)
     if USE_PACKED_FILTERS and not thin:
         pk = _packed_filter(lib, w, Cout, Cin, 1, stride)

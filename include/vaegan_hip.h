@@ -129,6 +129,16 @@ size_t vg_convT5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H, int W, i
 int vg_convT5x5_fwd_bf16split(const float* x, const void* packed, const float* bias, float* y,
                            int B, int Cin, int H, int W, int Cout, int stride, int planes,
                            void* workspace, size_t workspace_bytes, const vg_conv_fusion* fuse, void* stream);
+/* Stride-1 transposed convolution 32 -> (1..3) channels in the same arithmetic, on the PLAIN filter w (Cin, Cout, 5, 5):
+ * the decoder's last layer (ConvTranspose2d(32, 3, 5, 1, 2), /root/reference/models/model.py:507) and the data
+ * gradient of the discriminator's first layer (model.py:389).  One pass over x with the filter resident in registers
+ * (csrc/conv_thin_mfma.hip).  in_scale / in_shift / in_act: x is read as act(x * in_scale[ci] + in_shift[ci]) (the
+ * producing layer's BatchNorm + activation, vg_conv_fusion semantics); NULL: as it is.  _ok: 1 when the shape is taken
+ * (Cin == 32, Cout <= 3, W a multiple of 16 up to 128); otherwise use vg_convT5x5_fwd. */
+int vg_convT5x5_s1_thin_bf16split_ok(int Cin, int H, int W, int Cout);
+int vg_convT5x5_s1_thin_bf16split(const float* x, const float* w, const float* bias, float* y, int B, int Cin,
+                                  int H, int W, int Cout, int planes, const float* in_scale, const float* in_shift,
+                                  int in_act, void* stream);
 /* vg_conv5x5_wgrad in the same arithmetic.  The reduction runs over images in groups of 16: gy is re-laid
  * batch-innermost inside the call (B zero-padded to a multiple of 16), x is staged straight from NCHW; needs
  * OW % 8 == 0 -- the workspace query returns 0 for shapes it does not take (use vg_conv5x5_wgrad).

@@ -691,6 +691,33 @@ def test_bn_coefficients_from_stats_and_from_pass(H):
         assert_close(out, ref["y"], 3e-6, how + " normalised output")
 
 
+# ------------------------------------------------------------------ 3-channel edge layers on the MFMA (conv_thin_mfma.hip)
+@pytest.mark.parametrize("B,Cout,Hs,Ws", [(3, 3, 64, 64), (2, 3, 21, 16), (2, 1, 5, 48), (1, 2, 40, 128), (5, 3, 1, 32)])
+@pytest.mark.parametrize("act", [None, 1, 2])
+def test_convT_thin_split(H, B, Cout, Hs, Ws, act):
+    """vg_convT5x5_s1_thin_bf16split (32 -> <= 3 channels, stride 1: deconv4 and the data gradient of convs.0) against
+    the fp64 oracle at the convolutions' tolerance, plain and with a producer's BatchNorm + activation applied on load;
+    heights off the 16-row band grid, one-row images, every width class."""
+    g = torch.Generator().manual_seed(90)
+    x = torch.randn(B, 32, Hs, Ws, generator=g)
+    w = torch.randn(32, Cout, 5, 5, generator=g) * 0.05
+    bias = torch.randn(Cout, generator=g)
+    lib = __import__("disentangle_mlp_amd._lib", fromlist=["load"]).load()
+    assert lib.vg_convT5x5_s1_thin_bf16split_ok(32, Hs, Ws, Cout) == 1
+    assert lib.vg_convT5x5_s1_thin_bf16split_ok(16, Hs, Ws, Cout) == 0 and lib.vg_convT5x5_s1_thin_bf16split_ok(32, Hs, 24, Cout) == 0
+    tol = CONV_TOL if os.environ.get("VG_CONV_ARITH", "bf16x6") != "bf16x3" else 2e-5
+    if act is None:
+        ref = O.convT5x5(x, w, bias, 1)
+        assert_close(H.convT5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), 1), ref, tol, "thin convT")
+    else:
+        scale, shift = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g)
+        xa = x.double() * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+        xa = xa.clamp(min=0) if act == 1 else torch.where(xa > 0, xa, 0.2 * xa)
+        ref = O.convT5x5(xa, w, bias, 1)
+        y = H.convT5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), 1, in_affine=(scale.cuda(), shift.cuda(), act))
+        assert_close(y, ref, tol, "thin convT, BatchNorm + activation on load")
+
+
 # ------------------------------------------------------------------ Linear layers on the split-bf16 GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 2048, 16384), (128, 16384, 128), (4, 2048, 16384), (96, 200, 160), (32, 130, 64)])
 def test_linear_split_gemms(H, M, N, K, monkeypatch):
