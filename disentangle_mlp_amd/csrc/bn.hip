@@ -456,8 +456,10 @@ extern "C" int vg_bn_finalize_stats(const float* stats, int nslots, int C, doubl
   if (!stats || nslots <= 0 || C <= 0 || count <= 0 || !gamma || !beta || !save_mean || !save_invstd || !scale || !shift)
     return VG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
-  // few slots per channel block: one launch; many: NS_MAX-way first stage into the BatchNorm workspace
-  if ((long)nslots * cdiv(C, 32) <= 4096) {
+  // few slots: one launch (a workgroup per 32 channels, 8 partial-lanes: up to 8 dependent loads per lane); more:
+  // NS_MAX-way first stage into the BatchNorm workspace.  (The one-launch form on 1024 slots x 32 channels ran 56 us
+  // -- one workgroup, 128 dependent loads per lane -- against ~6 us for the two stages.)
+  if (nslots <= 64) {
     hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(cdiv(C, 32)), dim3(NT), 0, st, stats, nslots, 1L, (long)C, C,
                        count, gamma, beta, running_mean, running_var, save_mean, save_invstd, scale, shift, eps,
                        momentum);      // stats[slot][C][2]: channel stride 1, slot stride C

@@ -76,8 +76,10 @@ __global__ __launch_bounds__(512) void convT_s1_thin_mfma_kernel(TArgs A) {
     for (int kh = 0; kh < 5; ++kh) {
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        v[j] = (m < COUT * 5) ? A.w[((size_t)(kblk * 8 + j) * COUT + min(co, COUT - 1)) * 25 + kh * 5 + kw] : 0.f;
+      for (int j = 0; j < 8; ++j) {
+        const float t = A.w[((kblk * 8 + j) * COUT + min(co, COUT - 1)) * 25 + kh * 5 + kw];   // read, then select
+        v[j] = (m < COUT * 5) ? t : 0.f;
+      }
       split_frag<NP>(v, bf[kh]);
     }
   }
@@ -135,18 +137,28 @@ __global__ __launch_bounds__(512) void convT_s1_thin_mfma_kernel(TArgs A) {
         split_row(u, r0 - 2 + s);
         if (s >= 4) {
           const int oh = r0 + s - 4;
-          // one accumulator per product class (plane index sum): three independent MFMA chains instead of one of 30,
-          // added smallest class first
+          // one accumulator per product class (plane index sum), issued so that no MFMA accumulates into the result
+          // of the one just before it (that dependency is waited out in compiler-inserted s_nops); added smallest
+          // class first
           f32x4 dc[NP];
 #pragma unroll
           for (int c = 0; c < NP; ++c) dc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int kh = 0; kh < 5; ++kh)                            // input row oh + 2 - kh = step s - kh
-#pragma unroll
-            for (int sum = NP - 1; sum >= 0; --sum)
-#pragma unroll
-              for (int pa = sum; pa >= 0; --pa)
-                dc[sum] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(win[(u + 5 - kh) % 5][pa], bf[kh][sum - pa], dc[sum], 0, 0, 0);
+          for (int kh = 0; kh < 5; ++kh) {                          // input row oh + 2 - kh = step s - kh
+            const bf16x8* a = win[(u + 5 - kh) % 5];
+            if constexpr (NP == 3) {                                // classes 2 1 2 0 2 1
+              dc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], bf[kh][0], dc[2], 0, 0, 0);
+              dc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bf[kh][0], dc[1], 0, 0, 0);
+              dc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bf[kh][1], dc[2], 0, 0, 0);
+              dc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bf[kh][0], dc[0], 0, 0, 0);
+              dc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bf[kh][2], dc[2], 0, 0, 0);
+              dc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bf[kh][1], dc[1], 0, 0, 0);
+            } else {                                                // classes 1 0 1
+              dc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bf[kh][0], dc[1], 0, 0, 0);
+              dc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bf[kh][0], dc[0], 0, 0, 0);
+              dc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bf[kh][1], dc[1], 0, 0, 0);
+            }
+          }
           f32x4 d = dc[NP - 1];
 #pragma unroll
           for (int c = NP - 2; c >= 0; --c) d += dc[c];

@@ -268,6 +268,14 @@ def conv5x5_fwd(x, w, bias, stride, in_affine=None, want_stats=False):
                   "vg_conv5x5_fwd_bf16split")
         return (y, stats) if want_stats else y
     x = _materialize(x, in_affine)
+    if _planes() and THIN_SPLIT and Cin <= 3 and lib.vg_conv5x5_thin_bf16split_ok(Cin, H, W, Cout, stride):
+        # <= 3 input channels: filter resident in registers, one write pass over y, statistics on the way out
+        n = lib.vg_conv5x5_thin_bf16split_stats_floats(B, Cin, H, W, Cout, stride) if want_stats else 0
+        stats = torch.empty(n, dtype=torch.float32, device=x.device) if n else None
+        with _timed(("conv_fwd", B, Cin, H, W, Cout, stride)):
+            check(lib.vg_conv5x5_thin_bf16split(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W, Cout,
+                                                stride, _planes(), _ptr(stats), n, _stream()), "vg_conv5x5_thin_bf16split")
+        return (y, stats) if want_stats else y
     if USE_PACKED_FILTERS:
         pk = _packed_filter(lib, w, Cout, Cin, 0, stride)
         # The exact-fp32 kernel can leave the next BatchNorm's statistics too (vg_conv5x5_fwd_packed_stats), but on the

@@ -4,6 +4,7 @@
 #   ring: conv_ring.hip,       -DVG_RING_ABL=<bits>
 #   wx:   wgrad_bf16split.hip, -DVG_WX_ABL=<bits>
 #   gemm: gemm_split.hip,      -DVG_GEMM_ABL=<bits>
+#   tfwd: conv_thin_fwd.hip,   -DVG_TF_ABL=<bits>
 set -e
 cd "$(dirname "$0")/.."
 C=disentangle_mlp_amd/csrc
@@ -12,7 +13,8 @@ case $which in
   ring) SRC=conv_ring; DEF=VG_RING_ABL ;;
   wx)   SRC=wgrad_bf16split; DEF=VG_WX_ABL ;;
   gemm) SRC=gemm_split; DEF=VG_GEMM_ABL ;;
-  *) echo "usage: $0 <ring|wx|gemm> <bits> ..."; exit 2 ;;
+  tfwd) SRC=conv_thin_fwd; DEF=VG_TF_ABL ;;
+  *) echo "usage: $0 <ring|wx|gemm|tfwd> <bits> ..."; exit 2 ;;
 esac
 mkdir -p experiments/abl
 OBJS=$(ls $C/build/*.o | grep -v "/$SRC.o")

@@ -139,6 +139,17 @@ int vg_convT5x5_s1_thin_bf16split_ok(int Cin, int H, int W, int Cout);
 int vg_convT5x5_s1_thin_bf16split(const float* x, const float* w, const float* bias, float* y, int B, int Cin,
                                   int H, int W, int Cout, int planes, const float* in_scale, const float* in_shift,
                                   int in_act, void* stream);
+/* Convolution from 1..3 input channels in the same arithmetic, on the PLAIN filter w (Cout, Cin, 5, 5): the first
+ * layers of the discriminator (Conv2d(3, 32, 5, 1, 2), model.py:389) and the encoder (Conv2d(3, 64, 5, 2, 2),
+ * model.py:450).  One write pass over y with the filter resident in registers (csrc/conv_thin_fwd.hip); `stats`
+ * (or NULL) receives the per-channel partial sums of y for the BatchNorm that follows, vg_conv_fusion.stats layout
+ * ([slot][Cout][2], vg_conv5x5_thin_bf16split_stats_floats(...) floats, slots = floats / (2 Cout)).  _ok: 1 when the
+ * shape is taken (output width a multiple of 32, (output width / 32) * ceil(Cout / 32) <= 8); otherwise use
+ * vg_conv5x5_fwd. */
+int vg_conv5x5_thin_bf16split_ok(int Cin, int H, int W, int Cout, int stride);
+size_t vg_conv5x5_thin_bf16split_stats_floats(int B, int Cin, int H, int W, int Cout, int stride);
+int vg_conv5x5_thin_bf16split(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
+                              int Cout, int stride, int planes, float* stats, size_t stats_floats, void* stream);
 /* vg_conv5x5_wgrad in the same arithmetic.  The reduction runs over images in groups of 16: gy is re-laid
  * batch-innermost inside the call (B zero-padded to a multiple of 16), x is staged straight from NCHW; needs
  * OW % 8 == 0 -- the workspace query returns 0 for shapes it does not take (use vg_conv5x5_wgrad).

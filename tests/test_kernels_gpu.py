@@ -718,6 +718,32 @@ def test_convT_thin_split(H, B, Cout, Hs, Ws, act):
         assert_close(y, ref, tol, "thin convT, BatchNorm + activation on load")
 
 
+@pytest.mark.parametrize("B,Cin,Cout,Hs,Ws,stride", [(3, 3, 32, 64, 64, 1), (2, 3, 64, 64, 64, 2), (2, 1, 32, 9, 32, 1),
+                                                      (1, 2, 20, 5, 64, 1), (2, 3, 70, 14, 128, 2), (1, 3, 32, 30, 256, 1),
+                                                      (2, 3, 64, 128, 128, 2)])
+def test_conv_thin_split(H, B, Cin, Cout, Hs, Ws, stride):
+    """vg_conv5x5_thin_bf16split (<= 3 input channels: convs.0, features.0) against the fp64 oracle at the
+    convolutions' tolerance, and its statistics slots against the sums of its own output; heights off the band grid,
+    channel counts off the 32-channel groups, 1 and 2 input channels."""
+    g = torch.Generator().manual_seed(91)
+    x = torch.randn(B, Cin, Hs, Ws, generator=g)
+    w = torch.randn(Cout, Cin, 5, 5, generator=g) * 0.1
+    bias = torch.randn(Cout, generator=g)
+    lib = __import__("disentangle_mlp_amd._lib", fromlist=["load"]).load()
+    assert lib.vg_conv5x5_thin_bf16split_ok(Cin, Hs, Ws, Cout, stride) == 1
+    assert lib.vg_conv5x5_thin_bf16split_ok(4, Hs, Ws, Cout, stride) == 0
+    tol = CONV_TOL if os.environ.get("VG_CONV_ARITH", "bf16x6") != "bf16x3" else 2e-5
+    ref = O.conv5x5(x, w, bias, stride)
+    y, stats = H.conv5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), stride, want_stats=True)
+    assert_close(y, ref, tol, "thin conv")
+    assert stats is not None and stats.numel() % (2 * Cout) == 0
+    st = stats.view(-1, Cout, 2).double().sum(0).cpu()
+    yd = y.double().cpu()
+    assert_close(st[:, 0], yd.sum((0, 2, 3)), 1e-5, "statistics: sum y")
+    assert_close(st[:, 1], (yd * yd).sum((0, 2, 3)), 1e-5, "statistics: sum y^2")
+    assert_close(H.conv5x5_fwd(x.cuda(), w.cuda(), None, stride), O.conv5x5(x, w, None, stride), tol, "thin conv, no bias")
+
+
 # ------------------------------------------------------------------ Linear layers on the split-bf16 GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 2048, 16384), (128, 16384, 128), (4, 2048, 16384), (96, 200, 160), (32, 130, 64)])
 def test_linear_split_gemms(H, M, N, K, monkeypatch):
