@@ -378,11 +378,21 @@ def conv5x5_wgrad(x, gy, stride, out=None, in_affine=None, affine_on_gy=False):
                                                   _planes(), ws.data_ptr(), ws.numel(), _ptr(sc), _ptr(sh), int(act),
                                                   1 if affine_on_gy else 0, _stream()), "vg_conv5x5_wgrad_bf16split")
             return dw
-    if in_affine is not None:      # the exact-fp32 kernel takes the operand as a tensor
+    if in_affine is not None:      # the kernels below take the operand as a tensor
         if affine_on_gy:
             gy = _materialize(gy, in_affine)
         else:
             x = _materialize(x, in_affine)
+    if _planes() and THIN_SPLIT and Cin <= 3:
+        # <= 3 input channels: one read pass over gy, x split once per workgroup into shifted plane copies in LDS
+        need = lib.vg_conv5x5_thin_wgrad_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride, _planes())   # 0: shape not taken
+        if need:
+            ws = workspace(need, x.device)
+            with _timed(("conv_wgrad", B, Cin, H, W, Cout, stride)):
+                check(lib.vg_conv5x5_thin_wgrad_bf16split(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout,
+                                                          stride, _planes(), ws.data_ptr(), ws.numel(), _stream()),
+                      "vg_conv5x5_thin_wgrad_bf16split")
+            return dw
     need = lib.vg_conv5x5_wgrad_workspace_bytes(B, Cin, H, W, Cout, stride)
     ws = workspace(need, x.device)
     with _timed(("conv_wgrad", B, Cin, H, W, Cout, stride)):

@@ -150,6 +150,13 @@ int vg_conv5x5_thin_bf16split_ok(int Cin, int H, int W, int Cout, int stride);
 size_t vg_conv5x5_thin_bf16split_stats_floats(int B, int Cin, int H, int W, int Cout, int stride);
 int vg_conv5x5_thin_bf16split(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
                               int Cout, int stride, int planes, float* stats, size_t stats_floats, void* stream);
+/* ... and its weight gradient (dw (Cout, Cin, 5, 5), Cin <= 3, Cout <= 64; also the decoder's ConvTranspose2d(32, 3)
+ * with the roles of x and gy swapped): one read pass over gy, x split once per workgroup into shifted bf16 plane
+ * copies in LDS (csrc/conv_thin_wgrad.hip).  The workspace query returns 0 for shapes it does not take (output width
+ * not a multiple of 16, ...): use vg_conv5x5_wgrad then.  workspace: 16-byte aligned; gy 16-byte aligned. */
+size_t vg_conv5x5_thin_wgrad_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride, int planes);
+int vg_conv5x5_thin_wgrad_bf16split(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W, int Cout,
+                                    int stride, int planes, void* workspace, size_t workspace_bytes, void* stream);
 /* vg_conv5x5_wgrad in the same arithmetic.  The reduction runs over images in groups of 16: gy is re-laid
  * batch-innermost inside the call (B zero-padded to a multiple of 16), x is staged straight from NCHW; needs
  * OW % 8 == 0 -- the workspace query returns 0 for shapes it does not take (use vg_conv5x5_wgrad).

@@ -744,6 +744,29 @@ def test_conv_thin_split(H, B, Cin, Cout, Hs, Ws, stride):
     assert_close(H.conv5x5_fwd(x.cuda(), w.cuda(), None, stride), O.conv5x5(x, w, None, stride), tol, "thin conv, no bias")
 
 
+@pytest.mark.parametrize("B,Cin,Cout,Hs,Ws,stride", [(3, 3, 32, 64, 64, 1), (2, 3, 64, 64, 64, 2), (5, 1, 32, 9, 16, 1),
+                                                      (2, 2, 20, 21, 48, 1), (3, 3, 40, 14, 128, 2), (1, 3, 32, 40, 256, 1),
+                                                      (2, 3, 64, 128, 128, 2)])
+def test_conv_thin_wgrad_split(H, B, Cin, Cout, Hs, Ws, stride):
+    """vg_conv5x5_thin_wgrad_bf16split (<= 3 input channels: convs.0, features.0, and deconv4 with the roles swapped)
+    against the fp64 oracle at the convolutions' tolerance; heights off the band grid, channel counts off the 32-channel
+    groups, several bands per workgroup (B * bands > 256 at the last shape), and run twice (same bits: slab sums are
+    ordered)."""
+    g = torch.Generator().manual_seed(92)
+    x = torch.randn(B, Cin, Hs, Ws, generator=g)
+    OH, OW = (Hs - 1) // stride + 1, (Ws - 1) // stride + 1
+    gy = torch.randn(B, Cout, OH, OW, generator=g)
+    lib = __import__("disentangle_mlp_amd._lib", fromlist=["load"]).load()
+    planes = 2 if os.environ.get("VG_CONV_ARITH", "bf16x6") == "bf16x3" else 3
+    assert lib.vg_conv5x5_thin_wgrad_bf16split_workspace_bytes(B, Cin, Hs, Ws, Cout, stride, planes) > 0
+    assert lib.vg_conv5x5_thin_wgrad_bf16split_workspace_bytes(B, 4, Hs, Ws, Cout, stride, planes) == 0
+    tol = CONV_TOL if planes == 3 else 2e-5
+    _, gw_ref = O.conv5x5_grads(x, torch.zeros(Cout, Cin, 5, 5), gy, stride)
+    gw = H.conv5x5_wgrad(x.cuda(), gy.cuda(), stride)
+    assert_close(gw, gw_ref, tol, "thin wgrad")
+    assert torch.equal(gw, H.conv5x5_wgrad(x.cuda(), gy.cuda(), stride))
+
+
 # ------------------------------------------------------------------ Linear layers on the split-bf16 GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 2048, 16384), (128, 16384, 128), (4, 2048, 16384), (96, 200, 160), (32, 130, 64)])
 def test_linear_split_gemms(H, M, N, K, monkeypatch):
