@@ -25,6 +25,11 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 constexpr int WNT = 512;
+// timing experiments only (experiments/abl_build.sh twg <bits>): 1 every lane reads gy of channel 0 (one cache line per
+// load), 2 plane copies built for the first band only, 4 no MFMAs
+#ifndef VG_TWG_ABL
+#define VG_TWG_ABL 0
+#endif
 
 struct TWArgs {
   const float* x;
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(WNT) void conv_thin_wgrad_kernel(TWArgs A) {
     }
     __syncthreads();
     // ... then the five shifted plane copies.  Item = (kw, ci, input row, group): 8 pixels S apart.
-    {
+    if (!(VG_TWG_ABL & 2) || u == u_begin) {
       const int per_kc = rbi * ng, items = 15 * per_kc;
       const float inv_kc = 1.f / (float)per_kc;
       for (int e = tid; e < items; e += WNT) {
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(WNT) void conv_thin_wgrad_kernel(TWArgs A) {
       const int row = (int)(((float)st + 0.5f) * inv_kg), k16 = st - row * A.kg;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const int co = min(m * 32 + l32, Cout - 1);    // channels past Cout: clamped (their rows are not stored)
+        const int co = (VG_TWG_ABL & 1) ? 0 : min(m * 32 + l32, Cout - 1);    // channels past Cout: clamped (their rows are not stored)
         const float* p = gyb + ((size_t)co * OH + r0 + row) * OW + k16 * 16 + half * 8;
         const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
         raw[slot][m][0] = lo[0]; raw[slot][m][1] = lo[1]; raw[slot][m][2] = lo[2]; raw[slot][m][3] = lo[3];
@@ -167,7 +172,8 @@ __global__ __launch_bounds__(WNT) void conv_thin_wgrad_kernel(TWArgs A) {
           for (int pa = sum; pa >= 0; --pa)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
-              acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][pa], bf[sum - pa], acc[m][t], 0, 0, 0);
+              if (!(VG_TWG_ABL & 4)) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][pa], bf[sum - pa], acc[m][t], 0, 0, 0);
+              else acc[m][t][0] += (float)af[m][pa][0] + (float)bf[sum - pa][0];
       }
     };
     const int nmine = (nsteps > wid) ? (nsteps - wid + 7) / 8 : 0;     // steps wid, wid + 8, ...

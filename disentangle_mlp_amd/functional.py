@@ -134,11 +134,14 @@ class ConvStatsFn(Function):
         y, stats = conv(x, w, bias, stride, want_stats=True)
         stats = stats if stats is not None else x.new_empty(0)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)      # or autograd zero-fills a "gradient" of the statistics slots every backward
         return y, stats
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy, _):
+        if gy is None:
+            return (None,) * 6
         x, w = ctx.saved_tensors
         gy = gy.contiguous()
         s, tr = ctx.stride, ctx.transposed
@@ -179,11 +182,14 @@ class BNConvFn(Function):
         ctx.act, ctx.stride, ctx.transposed, ctx.bias_grad = act, stride, transposed, bias_grad
         ctx.save_for_backward(x, gamma, beta, mean, invstd, scale, shift, w)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)      # as ConvStatsFn
         return y, stats
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy, _):
+        if gy is None:
+            return (None,) * 14
         x, gamma, beta, mean, invstd, scale, shift, w = ctx.saved_tensors
         gy = gy.contiguous()
         s, tr, act = ctx.stride, ctx.transposed, ctx.act
@@ -254,11 +260,14 @@ class KLRowsFn(Function):
         z, _, rows = ops.reparam_kl_fwd(mu, logvar, eps, 1.0, want_rows=True)
         ctx.mark_non_differentiable(rows)
         ctx.save_for_backward(mu, logvar, eps)
+        ctx.set_materialize_grads(False)      # no zero-filled "gradient" of the rows
         return z, rows
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gz, _):
+        if gz is None:
+            return None, None, None
         mu, logvar, eps = ctx.saved_tensors
         gmu, glv = ops.reparam_kl_bwd(gz.contiguous(), mu, logvar, eps, None, 1.0)
         return gmu, glv, None

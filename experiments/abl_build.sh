@@ -5,6 +5,7 @@
 #   wx:   wgrad_bf16split.hip, -DVG_WX_ABL=<bits>
 #   gemm: gemm_split.hip,      -DVG_GEMM_ABL=<bits>
 #   tfwd: conv_thin_fwd.hip,   -DVG_TF_ABL=<bits>
+#   twg:  conv_thin_wgrad.hip, -DVG_TWG_ABL=<bits>
 set -e
 cd "$(dirname "$0")/.."
 C=disentangle_mlp_amd/csrc
@@ -14,7 +15,8 @@ case $which in
   wx)   SRC=wgrad_bf16split; DEF=VG_WX_ABL ;;
   gemm) SRC=gemm_split; DEF=VG_GEMM_ABL ;;
   tfwd) SRC=conv_thin_fwd; DEF=VG_TF_ABL ;;
-  *) echo "usage: $0 <ring|wx|gemm|tfwd> <bits> ..."; exit 2 ;;
+  twg)  SRC=conv_thin_wgrad; DEF=VG_TWG_ABL ;;
+  *) echo "usage: $0 <ring|wx|gemm|tfwd|twg> <bits> ..."; exit 2 ;;
 esac
 mkdir -p experiments/abl
 OBJS=$(ls $C/build/*.o | grep -v "/$SRC.o")
