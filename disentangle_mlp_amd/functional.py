@@ -68,14 +68,51 @@ class ConvT5x5Fn(Function):
         return gx, gw, gb, None, None
 
 
+class _DeferredWgrad:
+    """State of `deferred_wgrad()`: per big Linear weight, how many of its forward passes still owe a backward, and
+    the (gy, x) pairs of the ones already seen."""
+    active = False
+    pending = {}
+    stash = {}
+
+
+class deferred_wgrad:
+    """Context for a phase that runs a network several times and then ONE backward (the discriminator phase: D(x) and
+    D(fake), new_betavaegan.py:95-123): the weight gradient of a big Linear layer is computed once, over the
+    concatenated batches, by whichever of its backward nodes runs last -- instead of one GEMM per pass (each writing the
+    134 MB gradient of the 16384 x 2048 layer) plus autograd's additions.  The sum is the same up to fp32 summation
+    order.  Every forward made inside the context must get its backward inside it (checked at exit)."""
+
+    def __enter__(self):
+        _DeferredWgrad.active = DEFER_WGRAD
+        _DeferredWgrad.pending, _DeferredWgrad.stash = {}, {}
+        return self
+
+    def __exit__(self, *exc):
+        _DeferredWgrad.active = False
+        left = sum(_DeferredWgrad.pending.values())
+        _DeferredWgrad.pending, _DeferredWgrad.stash = {}, {}
+        if left and exc[0] is None:
+            raise RuntimeError(f"deferred_wgrad: {left} forward pass(es) of a Linear layer got no backward inside the context")
+        return False
+
+
+DEFER_MIN_WEIGHTS = 1 << 20
+DEFER_WGRAD = __import__("os").environ.get("VG_DEFER_WGRAD", "1") != "0"      # 0: deferred_wgrad() does nothing
+
+
 class LinearFn(Function):
-    """nn.Linear (model.py:460-471, 402-408, 490-492) on the split-bf16 GEMM (ops.linear_*: same fp32-equivalent
-    arithmetic as the convolutions); a GEMM whose reduction length is not a multiple of 32 -- the weight gradient at
-    batches that are not -- goes to the vendor library."""
+    """nn.Linear (model.py:460-471, 402-408, 490-492).  With ops.LINEAR_SPLIT on the split-bf16 GEMM (ops.linear_*: the
+    convolutions' fp32-equivalent arithmetic; a GEMM whose reduction length is not a multiple of 32 -- the weight
+    gradient at batches that are not -- goes to the vendor library), otherwise on the vendor fp32 GEMM.  Inside
+    `deferred_wgrad()` the weight gradient of a layer with >= 2^20 weights is batched over its passes."""
 
     @staticmethod
     def forward(ctx, x, w, bias):
         ctx.save_for_backward(x, w)
+        ctx.deferred = bool(_DeferredWgrad.active and ctx.needs_input_grad[1] and w.numel() >= DEFER_MIN_WEIGHTS)
+        if ctx.deferred:
+            _DeferredWgrad.pending[id(w)] = _DeferredWgrad.pending.get(id(w), 0) + 1
         if ops.linear_split_ok(x.shape[1]):
             return ops.linear_fwd(x, w, bias)
         return torch.nn.functional.linear(x, w, bias)
@@ -88,10 +125,22 @@ class LinearFn(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = ops.linear_dgrad(gy, w) if ops.linear_split_ok(gy.shape[1]) else gy @ w
-        if ctx.needs_input_grad[1]:
-            gw = ops.linear_wgrad(gy, x) if ops.linear_split_ok(gy.shape[0]) else gy.t() @ x
         if ctx.needs_input_grad[2]:
             gb = gy.sum(0)
+        if ctx.needs_input_grad[1]:
+            wg, wx = gy, x                                   # what the weight gradient is taken over
+            if ctx.deferred and _DeferredWgrad.active:
+                k = id(w)
+                _DeferredWgrad.stash.setdefault(k, []).append((gy, x))
+                _DeferredWgrad.pending[k] -= 1
+                if _DeferredWgrad.pending[k] > 0:
+                    wg = None                                # a later pass of this layer does it for all
+                else:
+                    pairs = _DeferredWgrad.stash.pop(k)
+                    if len(pairs) > 1:
+                        wg, wx = torch.cat([p[0] for p in pairs]), torch.cat([p[1] for p in pairs])
+            if wg is not None:
+                gw = ops.linear_wgrad(wg, wx) if ops.linear_split_ok(wg.shape[0]) else wg.t() @ wx
         return gx, gw, gb
 
 

@@ -155,7 +155,9 @@ class HipLinear(nn.Linear):
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("disentangle_mlp_amd modules need CUDA/ROCm tensors (no CPU fallback)")
-        if ops.LINEAR_SPLIT and self.weight.numel() >= (1 << 20) and x.dim() == 2:
+        # big layers go through this package's Function: the split GEMM when it is switched on, and the batched weight
+        # gradient of functional.deferred_wgrad() (the same vendor GEMMs otherwise)
+        if self.weight.numel() >= F.DEFER_MIN_WEIGHTS and x.dim() == 2:
             return F.linear(x, self.weight, self.bias)
         return tF.linear(x, self.weight, self.bias)
 

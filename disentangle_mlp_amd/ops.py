@@ -132,10 +132,12 @@ def conv_runs_split(op, cin, cout=None, stride=None):
     planes = _planes()
     if not planes:
         return False
+    if cin <= 3 and op in ("conv_fwd", "conv_wgrad"):
+        return THIN_SPLIT          # conv_thin_fwd.hip / conv_thin_wgrad.hip (shapes they take: output width % 32 / % 16)
     if op == "conv_wgrad":
         return WGRAD_SPLIT and cin >= (16 if planes == 2 else 32)
     if op == "convT_fwd" and stride == 1 and cout is not None and cout <= 4:
-        return False
+        return THIN_SPLIT and cin == 32 and cout <= 3          # conv_thin_mfma.hip
     return cin % 16 == 0
 
 

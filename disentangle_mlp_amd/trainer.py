@@ -280,12 +280,13 @@ class BetaVAEGANTrainer:
 
         # ---- phase 1: discriminator (:95-123)
         self._zero(netD, self.flat_d)
-        p_real, _ = netD(data)
-        err_real = F.bce_loss(p_real, real_label, gb)
         fake = netEG.decode(noise)                           # graph kept for phase 2 (:113)
-        p_fake, _ = netD(fake.detach())
-        err_fake = F.bce_loss(p_fake, fake_label, gb)
-        torch.autograd.backward([err_real, err_fake])
+        with F.deferred_wgrad():                             # D runs twice, one backward: big Linear weight gradient once
+            p_real, _ = netD(data)
+            err_real = F.bce_loss(p_real, real_label, gb)
+            p_fake, _ = netD(fake.detach())
+            err_fake = F.bce_loss(p_fake, fake_label, gb)
+            torch.autograd.backward([err_real, err_fake])
         self._exchange(self.flat_d)
         if grad_hook:
             grad_hook("D", netD)
@@ -493,12 +494,13 @@ class GANTrainer:
             noise = torch.randn(B, self.opt.n_hidden, device=self.device, generator=self.latent_generator)
         gb = global_batch if global_batch is not None else B * self.world
         self._zero(self.netD, self.flat_d)
-        p_real, _ = self.netD(data)
-        err_real = F.bce_loss(p_real, real_label, gb)
         fake = self.netG(noise)
-        p_fake, _ = self.netD(fake.detach())
-        err_fake = F.bce_loss(p_fake, fake_label, gb)
-        torch.autograd.backward([err_real, err_fake])
+        with F.deferred_wgrad():                             # as BetaVAEGANTrainer's discriminator phase
+            p_real, _ = self.netD(data)
+            err_real = F.bce_loss(p_real, real_label, gb)
+            p_fake, _ = self.netD(fake.detach())
+            err_fake = F.bce_loss(p_fake, fake_label, gb)
+            torch.autograd.backward([err_real, err_fake])
         self._exchange(self.flat_d)
         if grad_hook:
             grad_hook("D", self.netD)

@@ -175,3 +175,25 @@ def test_bucketed_overlapped_allreduce_two_ranks():
             flat = torch.cat([p.grad.flatten() for p in net.parameters()] + [torch.zeros(5)])
             want = flat if want is None else want + flat
         assert torch.allclose(got, want, rtol=1e-6, atol=1e-6)
+
+
+def test_deferred_linear_weight_gradient_is_the_sum_over_passes(monkeypatch):
+    """functional.deferred_wgrad(): a Linear layer applied twice before one backward gets ONE weight-gradient GEMM over
+    the concatenated passes (by whichever backward node runs last), the same gradients as autograd's two GEMMs + add;
+    a forward without its backward inside the context is an error."""
+    from disentangle_mlp_amd import functional as HF, ops
+    monkeypatch.setattr(ops, "LINEAR_SPLIT", False)
+    monkeypatch.setattr(HF, "DEFER_MIN_WEIGHTS", 1)
+    monkeypatch.setattr(HF, "DEFER_WGRAD", True)
+    torch.manual_seed(0)
+    w, b = torch.randn(6, 5, requires_grad=True), torch.randn(6, requires_grad=True)
+    x1, x2 = torch.randn(4, 5, requires_grad=True), torch.randn(3, 5)
+    ref = torch.nn.functional.linear(x1, w, b).pow(2).sum() + torch.nn.functional.linear(x2, w, b).sin().sum()
+    gw, gb, gx = torch.autograd.grad(ref, (w, b, x1))
+    with HF.deferred_wgrad():
+        y = HF.linear(x1, w, b).pow(2).sum() + HF.linear(x2, w, b).sin().sum()
+        y.backward()
+    assert torch.allclose(w.grad, gw, rtol=1e-5, atol=1e-5) and torch.allclose(b.grad, gb) and torch.allclose(x1.grad, gx)
+    with pytest.raises(RuntimeError, match="got no backward"):
+        with HF.deferred_wgrad():
+            HF.linear(x1, w, b)
