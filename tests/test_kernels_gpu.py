@@ -767,6 +767,22 @@ def test_conv_thin_wgrad_split(H, B, Cin, Cout, Hs, Ws, stride):
     assert torch.equal(gw, H.conv5x5_wgrad(x.cuda(), gy.cuda(), stride))
 
 
+def test_thin_kernels_bf16x3(H):
+    """The three 3-channel kernels with two planes (the opt-in bf16x3 arithmetic): 2e-5 against the fp64 oracle."""
+    g = torch.Generator().manual_seed(93)
+    x3, x32 = torch.randn(2, 3, 32, 32, generator=g), torch.randn(2, 32, 32, 32, generator=g)
+    w32, wT = torch.randn(32, 3, 5, 5, generator=g) * 0.1, torch.randn(32, 3, 5, 5, generator=g) * 0.05
+    prev = H.CONV_ARITH
+    try:
+        H.CONV_ARITH = "bf16x3"
+        assert_close(H.conv5x5_fwd(x3.cuda(), w32.cuda(), None, 1), O.conv5x5(x3, w32, None, 1), 2e-5, "thin conv, 2 planes")
+        assert_close(H.convT5x5_fwd(x32.cuda(), wT.cuda(), None, 1), O.convT5x5(x32, wT, None, 1), 2e-5, "thin convT, 2 planes")
+        _, gw_ref = O.conv5x5_grads(x3, w32, x32, 1)
+        assert_close(H.conv5x5_wgrad(x3.cuda(), x32.cuda(), 1), gw_ref, 2e-5, "thin wgrad, 2 planes")
+    finally:
+        H.CONV_ARITH = prev
+
+
 # ------------------------------------------------------------------ Linear layers on the split-bf16 GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 2048, 16384), (128, 16384, 128), (4, 2048, 16384), (96, 200, 160), (32, 130, 64)])
 def test_linear_split_gemms(H, M, N, K, monkeypatch):
