@@ -310,8 +310,8 @@ def main():
             "host_enqueue_ms_per_step": round(host_ms, 3),     # Python + launch calls only: below ms_per_step = GPU-bound
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32" if arith == "fp32" else
-                     "fp32-equivalent (%s split of fp32 operands on the bf16 MFMA, fp32 accumulate; 3-channel layers and "
-                     "everything else fp32)" % arith if arith == "bf16x6" else
+                     "fp32-equivalent (%s split of fp32 operands on the bf16 MFMA, fp32 accumulate, every convolution; "
+                     "Linear layers, BatchNorm, losses, Adam in fp32)" % arith if arith == "bf16x6" else
                      arith + " (split-bf16 operands on the bf16 MFMA, fp32 accumulate) + fp32 elsewhere",
             "arithmetic": ARITH_NOTE[arith],
             "data": "synthetic",

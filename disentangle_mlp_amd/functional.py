@@ -113,7 +113,7 @@ class LinearFn(Function):
         ctx.deferred = bool(_DeferredWgrad.active and ctx.needs_input_grad[1] and w.numel() >= DEFER_MIN_WEIGHTS)
         if ctx.deferred:
             _DeferredWgrad.pending[id(w)] = _DeferredWgrad.pending.get(id(w), 0) + 1
-        if ops.linear_split_ok(x.shape[1]):
+        if ops.linear_split_ok(x.shape[1], w.numel()):
             return ops.linear_fwd(x, w, bias)
         return torch.nn.functional.linear(x, w, bias)
 
@@ -124,7 +124,7 @@ class LinearFn(Function):
         gy = gy.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = ops.linear_dgrad(gy, w) if ops.linear_split_ok(gy.shape[1]) else gy @ w
+            gx = ops.linear_dgrad(gy, w) if ops.linear_split_ok(gy.shape[1], w.numel()) else gy @ w
         if ctx.needs_input_grad[2]:
             gb = gy.sum(0)
         if ctx.needs_input_grad[1]:
@@ -140,7 +140,7 @@ class LinearFn(Function):
                     if len(pairs) > 1:
                         wg, wx = torch.cat([p[0] for p in pairs]), torch.cat([p[1] for p in pairs])
             if wg is not None:
-                gw = ops.linear_wgrad(wg, wx) if ops.linear_split_ok(wg.shape[0]) else wg.t() @ wx
+                gw = ops.linear_wgrad(wg, wx) if ops.linear_split_ok(wg.shape[0], w.numel()) else wg.t() @ wx
         return gx, gw, gb
 
 

@@ -421,9 +421,14 @@ def _gemm_nt(A, B, bias, C, M, N, K, ars, aks, brs, bks):
     return C
 
 
-def linear_split_ok(reduction):
-    """The split-bf16 GEMM takes a Linear GEMM when the active arithmetic is a split one and the reduction length
-    is a multiple of 32."""
+LINEAR_SPLIT_MAX_WEIGHTS = int(os.environ.get("VG_LINEAR_SPLIT_MAX", "0"))     # > 0: only layers with at most this many weights
+
+
+def linear_split_ok(reduction, nweights=0):
+    """The split-bf16 GEMM takes a Linear GEMM when it is switched on, the active arithmetic is a split one, the
+    reduction length is a multiple of 32 and the layer is not above LINEAR_SPLIT_MAX_WEIGHTS (when that is set)."""
+    if LINEAR_SPLIT_MAX_WEIGHTS > 0 and nweights > LINEAR_SPLIT_MAX_WEIGHTS:
+        return False
     return LINEAR_SPLIT and bool(_planes()) and reduction % 32 == 0
 
 
