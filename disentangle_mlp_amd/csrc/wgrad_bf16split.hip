@@ -321,7 +321,10 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
               if (!(VG_WX_ABL & 8)) acc[f] = mfma_bf16(av[t & PD][pa], bv[f][sum - pa], acc[f]);
               else acc[f][0] += (float)av[t & PD][pa][0] + (float)bv[f][sum - pa][0];
             }
-        // one unit of the next patch per slot of the store schedule (the other buffer was last read a chunk ago)
+        // one unit of the next patch per slot of the store schedule (the other buffer was last read a chunk ago).
+        // (A branch-free form of this loop -- clamped re-loads instead of `more`, no wavefront groups, dump units for
+        // unit-less lanes: three basic blocks per chunk instead of ~40 -- measured 3-20 % SLOWER: hipcc clusters the
+        // MFMAs of the big block and the loads lose their run-ahead.)
         {
           const int rel = t - C::ST0;
           if (rel >= 0 && rel % C::STEP == 0 && rel / C::STEP < 2 * NQ) {
