@@ -77,7 +77,32 @@ __global__ __launch_bounds__(256) void relayout_gy_kernel(const float* __restric
   const int tid = threadIdx.x;
   const int p0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
   const int bg = blockIdx.z >> 1, kb = blockIdx.z & 1;
-  {
+  if ((P & 3) == 0 && p0 + 32 <= P && ((uintptr_t)gy & 15) == 0) {
+    // whole tile inside the image, rows 16-byte aligned: one 16-byte load per (image, channel, 4 pixels) -- 8 loads per
+    // thread in flight instead of 32 scalar ones
+    const int co = co0 + (tid >> 3), q4 = (tid & 7) * 4;
+    const float sc = (g_scale && co < Co) ? g_scale[co] : 1.f, sh = (g_scale && co < Co) ? g_shift[co] : 0.f;
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int b = bg * 16 + kb * 8 + j;
+      const float* src = gy + ((size_t)min(b, B - 1) * Co + min(co, Co - 1)) * P + p0 + q4;
+      v[j] = *reinterpret_cast<const f32x4*>(src);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = (bg * 16 + kb * 8 + j) < B && co < Co;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = v[j][e];
+        if (g_scale) {
+          t = fmaf(t, sc, sh);
+          t = fmaxf(t, 0.f) + g_slope * fminf(t, 0.f);
+        }
+        tile[j][tid >> 3][q4 + e] = ok ? t : 0.f;
+      }
+    }
+  } else {
     const int r = tid >> 5, pl = tid & 31;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
