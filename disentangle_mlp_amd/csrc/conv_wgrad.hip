@@ -249,8 +249,17 @@ __global__ __launch_bounds__(64 * NW) void wgrad_reduce_kernel(const float* __re
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
   float s = 0.f;
-  if (i < n)
-    for (int k = wid; k < splits; k += NW) s += ws[(size_t)k * n + i];
+  if (i < n) {
+    int k = wid;
+    for (; k + 3 * NW < splits; k += 4 * NW) {        // four slabs with their loads in flight together, added in slab order
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = ws[(size_t)(k + j * NW) * n + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += v[j];
+    }
+    for (; k < splits; k += NW) s += ws[(size_t)k * n + i];
+  }
   red[wid][lane] = s;
   __syncthreads();
 #pragma unroll

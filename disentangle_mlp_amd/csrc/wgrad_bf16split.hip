@@ -386,8 +386,18 @@ __global__ __launch_bounds__(256) void wx_reduce_kernel(const float* __restrict_
   const int row = Cin * 25, co = e / row, ci = (e - co * row) / 25;
   const long tile = (long)(ci / WCIT) * mtiles + co / tco;
   const int first = (int)((tile * chunks) / upw), last = (int)(((tile + 1) * chunks - 1) / upw);
+  // whole groups of four pieces with their loads in flight together, then the tail; added in piece order either way
+  const int cnt = last - first + 1;
   float sum = 0.f;
-  for (int p = 0; p <= last - first; ++p) sum += slabs[(size_t)p * n + e];
+  int p = 0;
+  for (; p + 4 <= cnt; p += 4) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = slabs[(size_t)(p + k) * n + e];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sum += v[k];
+  }
+  for (; p < cnt; ++p) sum += slabs[(size_t)p * n + e];
   dw[e] = sum;
 }
 
