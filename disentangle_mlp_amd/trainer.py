@@ -153,6 +153,19 @@ class FlatGrads:
                           for p in self.params])
 
 
+_ONES = {}
+
+
+def _backward(losses):
+    """One backward of the summed scalar losses, seeded with a cached 1.0 per device (autograd otherwise fills a fresh
+    ones_like for every loss: 8 tiny launches per iteration)."""
+    dev = losses[0].device
+    one = _ONES.get(dev)
+    if one is None:
+        one = _ONES[dev] = torch.ones((), dtype=torch.float32, device=dev)
+    torch.autograd.backward(losses, grad_tensors=[one] * len(losses))
+
+
 def _make_adam(params, lr, fused, capturable=False):
     """Adam with the reference's defaults (new_betavaegan.py:49-50).  On the GPU the step runs on the
     hand-written kernel (optim.HipAdam, a torch.optim.Adam subclass: identical state_dict); ``capturable``
@@ -286,7 +299,7 @@ class BetaVAEGANTrainer:
             err_real = F.bce_loss(p_real, real_label, gb)
             p_fake, _ = netD(fake.detach())
             err_fake = F.bce_loss(p_fake, fake_label, gb)
-            torch.autograd.backward([err_real, err_fake])
+            _backward([err_real, err_fake])
         self._exchange(self.flat_d)
         if grad_hook:
             grad_hook("D", netD)
@@ -307,7 +320,7 @@ class BetaVAEGANTrainer:
         err_g_rec = F.bce_loss(p_rec, real_label, gb)
         sim = F.sim_loss(sim_rec, sim_real)
         mse2 = F.reconstruction_loss(recon, data)
-        torch.autograd.backward([err_g_fake, err_g_rec, sim, mse2])
+        _backward([err_g_fake, err_g_rec, sim, mse2])
         self._set_d_frozen(False)
         self._exchange(self.flat_eg)
         if grad_hook:
@@ -321,7 +334,7 @@ class BetaVAEGANTrainer:
         self._zero(netEG, self.flat_eg)
         recon, mu, logvar, kld = netEG.forward_with_kl(data, eps3, self.beta)
         mse3 = F.reconstruction_loss(recon, data)
-        torch.autograd.backward([kld, mse3])
+        _backward([kld, mse3])
         self._exchange(self.flat_eg)
         if grad_hook:
             grad_hook("EG3", netEG)
@@ -422,7 +435,7 @@ class VAETrainer:
             self.optimizer.zero_grad(set_to_none=True)
         recon, mu, logvar, kld = self.model.forward_with_kl(data, eps, self.beta)
         mse = F.reconstruction_loss(recon, data)
-        torch.autograd.backward([mse, kld])
+        _backward([mse, kld])
         if self.flat is not None:
             self.flat.finish()
         self.optimizer.step()
@@ -500,7 +513,7 @@ class GANTrainer:
             err_real = F.bce_loss(p_real, real_label, gb)
             p_fake, _ = self.netD(fake.detach())
             err_fake = F.bce_loss(p_fake, fake_label, gb)
-            torch.autograd.backward([err_real, err_fake])
+            _backward([err_real, err_fake])
         self._exchange(self.flat_d)
         if grad_hook:
             grad_hook("D", self.netD)
@@ -511,7 +524,7 @@ class GANTrainer:
             p.requires_grad_(False)
         p_fake2, _ = self.netD(fake)
         err_g = F.bce_loss(p_fake2, real_label, gb)
-        err_g.backward()
+        _backward([err_g])
         for p in self.netD.parameters():
             p.requires_grad_(True)
         self._exchange(self.flat_g)
