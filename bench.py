@@ -243,10 +243,25 @@ def main():
     conv_ms_profiled = sum(totals.values())
 
     # ---- timed region: exactly K steps, dominant kernel bracketed by HIP events
+    flats = [f for f in (tr.flat_d, tr.flat_eg) if f is not None]
+    for f in flats:
+        f.reset_stats()
+        f.time_finish = True
     ops.start_timing(only=dominant)
     elapsed, step_ms, out = timed_steps(args.steps)
     host_ms = timed_steps.host_ms
     dom_ms = ops.stop_timing().get(dominant, [])
+    comm = None
+    if world > 1:
+        ranks = torch.ones(1, device=dev)
+        dist.all_reduce(ranks)                  # how many ranks the transport really connects
+        comm = {"ranks_counted_by_all_reduce": int(ranks.item()),
+                "bytes_all_reduced_per_step": sum(f.bytes_reduced for f in flats) // args.steps,
+                "collectives_per_step": sum(f.collectives for f in flats) / args.steps,
+                "exposed_comm_ms_per_step": round(sum(f.exposed_ms() for f in flats) / args.steps, 3),
+                "backend": dist.get_backend()}
+    for f in flats:
+        f.time_finish = False
 
     # ---- informational: the same K steps in the other arithmetics (N = 1 only; NOT `value`)
     other = None
@@ -323,9 +338,15 @@ def main():
             "step_tflops_algorithmic": round(ALG_GFLOP_PER_IMAGE * value / world / 1e3, 2),
             "conv_path_frac_of_fp32_mfma_peak": round(ALG_CONV_GFLOP_PER_IMAGE * value / world / 1e3
                                                       / PEAK_FP32_MFMA_TFLOPS, 4),
+            # the same conv-path rate against the roof of the arithmetic the kernels actually run in (the dense bf16
+            # MFMA peak / MFMAs per fp32 multiply for the split modes): iteration level, everything else included
+            "conv_path_frac_of_own_roof": round(ALG_CONV_GFLOP_PER_IMAGE * value / world / 1e3 / (
+                PEAK_BF16_MFMA_TFLOPS / MFMAS_PER_PRODUCT[arith] if arith in MFMAS_PER_PRODUCT else PEAK_FP32_MFMA_TFLOPS), 4),
             "conv_ms_per_step_profiled": round(conv_ms_profiled, 3),
             "losses_finite": finite,
         }
+        if comm is not None:
+            res["data_parallel"] = comm
         if other is not None:
             res["other_arithmetics"] = other
         if world == 1 and not args.no_cpu_baseline:

@@ -14,6 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvaegan_hip.so")
+ABI_VERSION = 3      # VG_ABI_VERSION of include/vaegan_hip.h this binding was written against
 
 _P, _I, _F, _Z = c_void_p, c_int, c_float, c_size_t
 
@@ -98,6 +99,10 @@ def _open(path, signatures):
         fn = getattr(lib, name)   # AttributeError if the symbol is missing: loud by design
         fn.restype = res
         fn.argtypes = args
+    built = lib.vg_version()
+    if built != ABI_VERSION:      # a stale build product: same symbols, shifted arguments / old pack layouts
+        raise ImportError(f"{path} was built for ABI {built}, this package binds ABI {ABI_VERSION}: rebuild it with "
+                          "`python -m disentangle_mlp_amd.build`")
     return lib
 
 

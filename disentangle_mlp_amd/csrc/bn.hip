@@ -447,6 +447,16 @@ __global__ __launch_bounds__(NT) void affine_act_kernel(const float* __restrict_
   *reinterpret_cast<float4*>(y + e) = o;
 }
 
+// the same for H*W not a multiple of 4 (odd image sizes): one element per lane
+__global__ __launch_bounds__(NT) void affine_act_scalar_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, float* __restrict__ y,
+                                                               int C, int HW, size_t n, int act) {
+  const size_t e = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (e >= n) return;
+  const int c = (int)((e / HW) % C);
+  y[e] = act_fwd(fmaf(x[e], scale[c], shift[c]), act);
+}
+
 extern "C" size_t vg_bn_workspace_bytes(int C) { return C > 0 ? ws_bytes(C) : 0; }
 
 extern "C" int vg_bn_finalize_stats(const float* stats, int nslots, int C, double count, const float* gamma,
@@ -499,8 +509,16 @@ extern "C" int vg_bn_stats(const float* x, const float* gamma, const float* beta
 
 extern "C" int vg_affine_act(const float* x, const float* scale, const float* shift, float* y, int B, int C, int HW,
                              int act, void* stream) {
-  if (!x || !scale || !shift || !y || B <= 0 || C <= 0 || HW <= 0 || (HW & 3)) return VG_ERR_BAD_ARG;
+  if (!x || !scale || !shift || !y || B <= 0 || C <= 0 || HW <= 0) return VG_ERR_BAD_ARG;
   if (act < VG_ACT_NONE || act > VG_ACT_LRELU) return VG_ERR_BAD_ARG;
+  if (HW & 3) {
+    const size_t n = (size_t)B * C * HW;
+    if (cdiv((long)n, (long)NT) > 0x7fffffffL) return VG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(affine_act_scalar_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, x,
+                       scale, shift, y, C, HW, n, act);
+    VG_CHECK_LAUNCH();
+    return 0;
+  }
   const size_t n4 = (size_t)B * C * HW / 4;
   if (cdiv((long)n4, (long)NT) > 0x7fffffffL) return VG_ERR_BAD_ARG;
   hipLaunchKernelGGL(affine_act_kernel, dim3((unsigned)((n4 + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, x, scale,

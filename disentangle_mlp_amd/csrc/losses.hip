@@ -181,7 +181,7 @@ constexpr int SQ_PARTS = 1024;
 
 }  // namespace
 
-extern "C" int vg_version(void) { return 1; }
+extern "C" int vg_version(void) { return VG_ABI_VERSION; }
 
 extern "C" int vg_bias_act_fwd(const float* x, const float* bias, float* y, int B, int C, int HW, int act_kind,
                                void* stream) {

@@ -68,12 +68,7 @@ class ConvT5x5Fn(Function):
         return gx, gw, gb, None, None
 
 
-class _DeferredWgrad:
-    """State of `deferred_wgrad()`: per big Linear weight, how many of its forward passes still owe a backward, and
-    the (gy, x) pairs of the ones already seen."""
-    active = False
-    pending = {}
-    stash = {}
+_defer_tls = __import__("threading").local()      # .current: the innermost active deferred_wgrad context of this thread
 
 
 class deferred_wgrad:
@@ -81,17 +76,27 @@ class deferred_wgrad:
     D(fake), new_betavaegan.py:95-123): the weight gradient of a big Linear layer is computed once, over the
     concatenated batches, by whichever of its backward nodes runs last -- instead of one GEMM per pass (each writing the
     134 MB gradient of the 16384 x 2048 layer) plus autograd's additions.  The sum is the same up to fp32 summation
-    order.  Every forward made inside the context must get its backward inside it (checked at exit)."""
+    order.  Every forward made inside the context must get its backward inside it (checked at exit).
+
+    The bookkeeping (per big weight: forward passes that still owe a backward, and the (gy, x) pairs already seen)
+    lives in the context object, which every forward made inside it captures: two trainers stepping in two threads, or
+    a backward that runs after its context has closed, never see each other's state (such a late backward just
+    computes its own weight gradient)."""
+
+    def __init__(self):
+        self.pending, self.stash, self.open = {}, {}, False
 
     def __enter__(self):
-        _DeferredWgrad.active = DEFER_WGRAD
-        _DeferredWgrad.pending, _DeferredWgrad.stash = {}, {}
+        self._outer = getattr(_defer_tls, "current", None)
+        self.open = DEFER_WGRAD
+        _defer_tls.current = self if DEFER_WGRAD else None
         return self
 
     def __exit__(self, *exc):
-        _DeferredWgrad.active = False
-        left = sum(_DeferredWgrad.pending.values())
-        _DeferredWgrad.pending, _DeferredWgrad.stash = {}, {}
+        _defer_tls.current = self._outer
+        self.open = False
+        left = sum(self.pending.values())
+        self.pending, self.stash = {}, {}
         if left and exc[0] is None:
             raise RuntimeError(f"deferred_wgrad: {left} forward pass(es) of a Linear layer got no backward inside the context")
         return False
@@ -110,9 +115,10 @@ class LinearFn(Function):
     @staticmethod
     def forward(ctx, x, w, bias):
         ctx.save_for_backward(x, w)
-        ctx.deferred = bool(_DeferredWgrad.active and ctx.needs_input_grad[1] and w.numel() >= DEFER_MIN_WEIGHTS)
-        if ctx.deferred:
-            _DeferredWgrad.pending[id(w)] = _DeferredWgrad.pending.get(id(w), 0) + 1
+        dctx = getattr(_defer_tls, "current", None)
+        ctx.defer = dctx if (dctx is not None and ctx.needs_input_grad[1] and w.numel() >= DEFER_MIN_WEIGHTS) else None
+        if ctx.defer is not None:
+            dctx.pending[id(w)] = dctx.pending.get(id(w), 0) + 1
         if ops.linear_split_ok(x.shape[1], w.numel()):
             return ops.linear_fwd(x, w, bias)
         return torch.nn.functional.linear(x, w, bias)
@@ -129,14 +135,14 @@ class LinearFn(Function):
             gb = gy.sum(0)
         if ctx.needs_input_grad[1]:
             wg, wx = gy, x                                   # what the weight gradient is taken over
-            if ctx.deferred and _DeferredWgrad.active:
-                k = id(w)
-                _DeferredWgrad.stash.setdefault(k, []).append((gy, x))
-                _DeferredWgrad.pending[k] -= 1
-                if _DeferredWgrad.pending[k] > 0:
+            d, k = ctx.defer, id(w)
+            if d is not None and d.open and d.pending.get(k, 0) > 0:
+                d.stash.setdefault(k, []).append((gy, x))
+                d.pending[k] -= 1
+                if d.pending[k] > 0:
                     wg = None                                # a later pass of this layer does it for all
                 else:
-                    pairs = _DeferredWgrad.stash.pop(k)
+                    pairs = d.stash.pop(k)
                     if len(pairs) > 1:
                         wg, wx = torch.cat([p[0] for p in pairs]), torch.cat([p[1] for p in pairs])
             if wg is not None:
@@ -151,7 +157,7 @@ class BNActFn(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act, stats=None):
-        if stats is not None and (x.numel() // (x.shape[0] * x.shape[1])) % 4 == 0:
+        if stats is not None:
             count = x.numel() // x.shape[1]
             mean, invstd, scale, shift = ops.bn_finalize_stats(stats, count, gamma, beta, running_mean, running_var,
                                                                eps, momentum)

@@ -170,6 +170,16 @@ class HipLinear(nn.Linear):
 FUSE_CONV_BN = True
 
 
+def _has_hooks(mods):
+    """Forward (pre-)hooks on any of the modules, or registered globally: the fused chain calls the kernels of several
+    modules at once and would never fire them, so a hooked chain runs module by module instead (feature taps,
+    profilers and parity probes keep working; same numbers up to the summation order of the statistics)."""
+    from torch.nn.modules import module as _m
+    if _m._global_forward_hooks or _m._global_forward_pre_hooks:
+        return True
+    return any(m._forward_hooks or m._forward_pre_hooks for m in mods)
+
+
 def run_conv_bn_chain(mods, x):
     """Forward of [conv | transposed conv | HipBatchNorm2d | FusedIntoBN placeholder] modules in order, fused as
     above; a BatchNorm that is last in the chain (its consumer is not one of these convolutions) is materialised,
@@ -210,9 +220,10 @@ class FusedChain(nn.Sequential):
     (The class name must contain neither "Conv" nor "BatchNorm": weights_init matches class names, model.py:8-14.)"""
 
     def forward(self, x):
-        if not FUSE_CONV_BN:
+        mods = list(self)
+        if not FUSE_CONV_BN or _has_hooks(mods):
             return super().forward(x)
-        return run_conv_bn_chain(list(self), x)
+        return run_conv_bn_chain(mods, x)
 
 
 def _enc_trunk(cin, width):
@@ -259,9 +270,10 @@ class _DecoderMixin:
         bs = code.size(0)
         h = self.preprocess(code).view(-1, n_z[0], n_z[1], n_z[2])
         zh, zw = n_z[1], n_z[2]          # (8, 8) in the reference: the literals of model.py:558-564
-        if FUSE_CONV_BN:                 # deconv1 -> act1 -> deconv2 -> act2 -> deconv3 -> act3 -> deconv4 as one fused chain
-            h = run_conv_bn_chain([self.deconv1, *self.act1, self.deconv2, *self.act2, self.deconv3, *self.act3,
-                                   self.deconv4], h.contiguous())
+        chain = [self.deconv1, *self.act1, self.deconv2, *self.act2, self.deconv3, *self.act3, self.deconv4]
+        if FUSE_CONV_BN and not _has_hooks(chain + [self.act1, self.act2, self.act3]):
+            # deconv1 -> act1 -> deconv2 -> act2 -> deconv3 -> act3 -> deconv4 as one fused chain
+            h = run_conv_bn_chain(chain, h.contiguous())
             return self.activation(h)
         h = self.act1(self.deconv1(h, output_size=(bs, 256, 2 * zh, 2 * zw)))
         h = self.act2(self.deconv2(h, output_size=(bs, 128, 4 * zh, 4 * zw)))

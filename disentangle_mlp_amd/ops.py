@@ -525,8 +525,6 @@ def affine_act(x, scale, shift, act):
     _req(x, "x"), _req(scale, "scale"), _req(shift, "shift")
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
-    if HW % 4:
-        raise RuntimeError("affine_act: H*W must be a multiple of 4")
     y = torch.empty_like(x)
     check(lib.vg_affine_act(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), B, C, HW, int(act), _stream()),
           "vg_affine_act")

@@ -90,6 +90,10 @@ class FlatGrads:
         self._pending, self._launched, self._direct_done, self._handles = [], [], set(), []
         self._armed = False
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
+        # bookkeeping for bench.py: bytes handed to all-reduce since the last reset, and -- when `time_finish` is set --
+        # HIP-event pairs around the waits of finish() (how long the compute stream stood still for the exchange)
+        self.bytes_reduced, self.collectives = 0, 0
+        self.time_finish, self.finish_events = False, []
 
     def _make_hook(self, i):
         def hook(p):
@@ -110,11 +114,15 @@ class FlatGrads:
         if g is None or i in self._direct_done:
             return
         self._direct_done.add(i)
+        self.bytes_reduced += g.numel() * 4
+        self.collectives += 1
         self._handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
 
     def _launch(self, b):
         bk = self.buckets[b]
         self._launched[b] = True
+        self.bytes_reduced += (bk["end"] - bk["start"]) * 4
+        self.collectives += 1
         self._handles.append(dist.all_reduce(self.flat[bk["start"]:bk["end"]], op=dist.ReduceOp.SUM,
                                              async_op=True))
 
@@ -142,10 +150,28 @@ class FlatGrads:
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)
+        timed = self.time_finish and self.flat.is_cuda
+        if timed:
+            a = torch.cuda.Event(enable_timing=True)
+            a.record()
         for h in self._handles:
             h.wait()
+        if timed:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            self.finish_events.append((a, b))
         self._handles = []
         self._armed = False
+
+    def reset_stats(self):
+        self.bytes_reduced, self.collectives, self.finish_events = 0, 0, []
+
+    def exposed_ms(self):
+        """Sum over the recorded finish() calls of the time between the compute stream reaching the waits and passing
+        them (synchronises)."""
+        if self.finish_events:
+            torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self.finish_events)
 
     def gathered(self):
         """All gradients flattened in parameter order (tests / diagnostics; copies)."""
@@ -209,6 +235,14 @@ def sample_labels(rng=None):
     return float(real_label), float(fake_label)
 
 
+def _shared_label_rng(seed):
+    """Label stream of a data-parallel run.  The reference is ONE process: its draw of new_betavaegan.py:89-90 applies
+    to the whole global batch.  With one process per GPU every rank must make the same draw, so each trainer owns a
+    ``np.random.RandomState`` seeded alike on all ranks (NumPy's global stream, which the reference consumes and a
+    single-process run here still uses by default, is seeded nowhere and shared by nobody)."""
+    return np.random.RandomState((int(seed) + 0x5EED) % (2 ** 32))
+
+
 def _loader_global_batch(loader, local_batch, world):
     """Images of the current GLOBAL batch: what nn.BCELoss's mean runs over under the reference's
     DataParallel.  data.DeviceLoader publishes it (a short last batch is split unevenly over the
@@ -246,6 +280,7 @@ class BetaVAEGANTrainer:
         self._d_params = [p for p in self.netD.parameters() if p.dim() == 4]
         self.rank = _dist_rank()
         self.latent_generator = _latent_generator(self.device, seed, self.rank)
+        self.label_rng = _shared_label_rng(seed)          # used by train_epoch when world > 1: one draw per GLOBAL batch
 
     def draw_latents(self, batch):
         """One N(0,1) draw of shape (batch, n_hidden) from this replica's own stream."""
@@ -357,9 +392,13 @@ class BetaVAEGANTrainer:
         are divided by ``len(loader.dataset)``.  The sums live on the device; the host reads them once
         per epoch (the reference synchronises four times per iteration with ``.item()``).
         Under data parallelism the sums are all-reduced once at the end, so every rank returns the
-        global-batch values the reference's DataParallel run would log."""
+        global-batch values the reference's DataParallel run would log, and the labels come -- unless
+        ``label_rng`` is given -- from the trainer's own stream, seeded alike on every rank: one label pair
+        per global batch, as in the reference's single process."""
         acc = torch.zeros(2, dtype=torch.float64, device=self.device)     # [sum of mse_enc, sum of mean D(x)]
         n_it = 0
+        if label_rng is None and self.world > 1:
+            label_rng = self.label_rng                    # every rank the same label pair (see _shared_label_rng)
         for data, _ in loader:
             real_label, fake_label = sample_labels(label_rng)
             gb = _loader_global_batch(loader, data.size(0), self.world)
@@ -483,6 +522,7 @@ class GANTrainer:
         self.flat_g = FlatGrads(self.netG.parameters()) if self.dp else None
         self.flat_d = FlatGrads(self.netD.parameters()) if self.dp else None
         self.latent_generator = _latent_generator(self.device, seed, _dist_rank())
+        self.label_rng = _shared_label_rng(seed)
         self.netG.train()
         self.netD.train()
 
@@ -542,6 +582,8 @@ class GANTrainer:
         meant).  The sum of errD over the epoch is available as ``self.last_epoch_sums["errD"]``."""
         acc = torch.zeros(2, dtype=torch.float64, device=self.device)
         n_it = 0
+        if label_rng is None and self.world > 1:
+            label_rng = self.label_rng                    # as BetaVAEGANTrainer.train_epoch
         for data, _ in loader:
             real_label, fake_label = sample_labels(label_rng)
             gb = _loader_global_batch(loader, data.size(0), self.world)

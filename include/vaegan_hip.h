@@ -40,6 +40,11 @@ extern "C" {
 #define VG_ACT_RELU 1  /* nn.ReLU          model.py:452,463,493 */
 #define VG_ACT_LRELU 2 /* nn.LeakyReLU(.2) model.py:391,404     */
 
+/* ABI version of this header: bumped on every incompatible change of a signature, of a packed-filter layout or of a
+ * workspace contract.  vg_version() returns the value the library was built with; a binding must refuse a library
+ * whose version is not the header's (the .so files are build products that travel with the working tree: a stale one
+ * still exports every old symbol).  3: round 3. */
+#define VG_ABI_VERSION 3
 int vg_version(void);
 
 /* ---- 5x5 convolutions, padding 2, stride 1 or 2 ----------------------------
@@ -209,7 +214,7 @@ int vg_bn_act_bwd(const float* gy, const float* x, const float* gamma, const flo
  * -- save_mean / save_invstd for backward, scale = gamma * invstd and shift = beta - mean * scale for the consumer's
  * in_scale / in_shift -- and updates the running statistics (momentum, unbiased variance) as vg_bn_act_fwd does;
  * count = B * H * W.  vg_bn_stats does the same from a pass over x (layers whose producer cannot emit statistics).
- * vg_affine_act materialises y = act(x * scale[c] + shift[c]) (HW % 4 == 0) for consumers that cannot apply the
+ * vg_affine_act materialises y = act(x * scale[c] + shift[c]) (16-byte accesses when HW % 4 == 0) for consumers that cannot apply the
  * coefficients while they load. */
 int vg_bn_finalize_stats(const float* stats, int nslots, int C, double count, const float* gamma, const float* beta,
                          float* running_mean, float* running_var, float* save_mean, float* save_invstd,

@@ -51,11 +51,26 @@ def test_product_library_has_no_tuning_knobs(lib_path):
         assert getattr(tun, name) is not None, name
 
 
+def header_abi_version():
+    import re
+    with open(os.path.join(ROOT, "include", "vaegan_hip.h")) as f:
+        return int(re.search(r"#define\s+VG_ABI_VERSION\s+(\d+)", f.read()).group(1))
+
+
+def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
+    """The .so files are build products that travel with the working tree: one built before an incompatible change
+    still exports every symbol, so the binding compares vg_version() with the version it was written against."""
+    from disentangle_mlp_amd import _lib
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(ImportError, match="rebuild"):
+        _lib._open(_lib.LIB_PATH, _lib.SIGNATURES)
+
+
 def test_pure_host_entry_points(lib_path):
     """Workspace-size queries and argument validation run without a device."""
     from disentangle_mlp_amd import _lib
     lib = _lib.load()
-    assert lib.vg_version() == 1
+    assert lib.vg_version() == _lib.ABI_VERSION == header_abi_version()
     assert lib.vg_conv5x5_wgrad_workspace_bytes(128, 128, 32, 32, 256, 2) > 0
     assert lib.vg_conv5x5_wgrad_workspace_bytes(128, 128, 32, 32, 256, 3) == 0     # bad stride
     assert lib.vg_bn_workspace_bytes(256) >= 256 * 64 * 16

@@ -126,7 +126,7 @@ def test_rccl_path_in_a_group_of_one():
         dist.destroy_process_group()
         print("rccl-one-rank ok")
     """)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "rccl-one-rank ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
@@ -220,3 +220,10 @@ def test_bench_launches_two_ranks_on_this_gpu():
     assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2" and res["config"]["global_batch"] == 32
     assert res["steps"] == 2 and res["losses_finite"] and res["value"] > 0
     assert abs(res["value"] - 32 * 2 / (res["ms_per_step"] * 2e-3)) <= 0.01 * res["value"]     # whole-job images/s
+    # the line explains its own exchange: ranks the transport connected, payload per iteration (D once + EG twice:
+    # (36 122 945 + 2 x 73 385 795) fp32 parameters), time the compute stream stood still for it
+    dp = res["data_parallel"]
+    assert dp["ranks_counted_by_all_reduce"] == 2 and dp["backend"] == "gloo"
+    assert dp["bytes_all_reduced_per_step"] == 4 * (36122945 + 2 * 73385795)
+    assert dp["exposed_comm_ms_per_step"] >= 0 and dp["collectives_per_step"] >= 3
+    assert 0 < res["conv_path_frac_of_own_roof"] < res["conv_path_frac_of_fp32_mfma_peak"]

@@ -104,6 +104,51 @@ def test_sample_labels_follows_the_reference_draw():
     assert set(np.unique(draws)) == {0.1, 0.9}
 
 
+def _label_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from disentangle_mlp_amd.trainer import BetaVAEGANTrainer, GANTrainer
+    np.random.seed(1000 + rank)                  # whatever the ranks' global NumPy streams hold must not matter
+    seen = {}
+    for name, tr in (("vaegan", BetaVAEGANTrainer(device="cpu", seed=999)), ("gan", GANTrainer(device="cpu", seed=999))):
+        calls = []
+
+        def fake_step(data, real_label=None, fake_label=None, global_batch=None, _calls=calls, **kw):
+            _calls.append((real_label, fake_label, global_batch))
+            z = torch.tensor(0.0)
+            return {"mse_enc": z, "D_x_sum": z, "errG": z, "errD_real": z, "errD_fake": z}
+        tr.step = fake_step
+        loader = _Loader([torch.zeros(4, 3, 64, 64)] * 200, n=800 * world)
+        loader.last_global_batch = None
+        tr.train_epoch(loader)
+        seen[name] = calls
+    q.put((rank, seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_draw_the_same_labels_in_train_epoch():
+    """One label pair per GLOBAL batch (the reference is one process: new_betavaegan.py:89-90 / new_gan.py:68-69):
+    without an explicit ``label_rng`` every rank of a data-parallel run must draw the same soft / flipped labels."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_label_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for name in ("vaegan", "gan"):
+        a, b = got[0][name], got[1][name]
+        assert len(a) == len(b) == 200 and a == b
+        labels = {(r, f) for r, f, _ in a}
+        assert len(labels) > 1                                   # 200 draws at 5 % flips: not all (0.9, 0.1)
+        assert all(gb == 4 for _, _, gb in a)                    # _Loader publishes its own global batch
+
+
 # ------------------------------------------------------------------ epoch bookkeeping (:196-201)
 class _Loader:
     def __init__(self, batches, n):

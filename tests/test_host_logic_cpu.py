@@ -197,3 +197,38 @@ def test_deferred_linear_weight_gradient_is_the_sum_over_passes(monkeypatch):
     with pytest.raises(RuntimeError, match="got no backward"):
         with HF.deferred_wgrad():
             HF.linear(x1, w, b)
+    # a backward that runs after its context has closed computes its own weight gradient (no shared state to trip over)
+    w.grad = None
+    with pytest.raises(RuntimeError, match="got no backward"):
+        with HF.deferred_wgrad():
+            late = HF.linear(x2, w, b).sum()
+    late.backward()
+    assert torch.allclose(w.grad, torch.ones(3, 6).t() @ x2, rtol=1e-5, atol=1e-5)
+    # contexts nest and do not share state
+    w.grad = None
+    with HF.deferred_wgrad() as outer:
+        y1 = HF.linear(x2, w, b).sum()
+        with HF.deferred_wgrad() as inner:
+            y2 = HF.linear(x2, w, b).sum()
+            assert sum(inner.pending.values()) == 1 and sum(outer.pending.values()) == 1
+            y2.backward()
+        y1.backward()
+    assert torch.allclose(w.grad, 2 * torch.ones(3, 6).t() @ x2, rtol=1e-5, atol=1e-5)
+
+
+def test_fused_chain_falls_back_to_module_calls_when_hooked():
+    """model.FusedChain / the decoder chain call the kernels of several modules at once; with a forward hook on any of
+    them (a feature tap, a profiler) the chain must run module by module so that the hook fires."""
+    from disentangle_mlp_amd import model as M
+    from disentangle_mlp_amd.trainer import ModelOpt
+    d = M.Discriminator_celeba(ModelOpt())
+    mods = list(d.convs)
+    assert not M._has_hooks(mods)
+    h = d.convs[3].register_forward_hook(lambda m, i, o: None)
+    assert M._has_hooks(mods)
+    h.remove()
+    assert not M._has_hooks(mods)
+    h = d.convs[1].register_forward_pre_hook(lambda m, i: None)
+    assert M._has_hooks(mods)
+    h.remove()
+

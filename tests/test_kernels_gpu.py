@@ -289,10 +289,45 @@ def _dot(a, b):
     return float((a.double() * b.double()).sum())
 
 
+def _conv_corner_crops(y, x, w, bias, stride, prep=None, c=None, tol=3e-6, what="conv"):
+    """Spot check of a full-size convolution output against the fp64 oracle on crops no larger than the oracle
+    finishes in a second: the first two and the last image, top-left and bottom-right corners (receptive fields
+    that see the real zero padding, the first and the last tile of the launch).  ``prep``: fp64 transform of the
+    cropped input (a producer's BatchNorm + activation applied on load)."""
+    c = c or (12 if stride == 1 else 16)
+    B, Hs, Ws = x.shape[0], x.shape[2], x.shape[3]
+    k = (c - 2) // stride                       # output pixels whose 5x5 window stays inside the crop
+    for imgs in (slice(0, 2), slice(B - 1, B)):
+        for corner in ("tl", "br"):
+            xs = x[imgs, :, :c, :c] if corner == "tl" else x[imgs, :, Hs - c:, Ws - c:]
+            xs = xs.cpu().double()
+            ref = O.conv5x5(prep(xs) if prep else xs, w.cpu(), None if bias is None else bias.cpu(), stride)
+            got = (y[imgs, :, :k, :k] if corner == "tl" else y[imgs, :, -k:, -k:]).cpu().double()
+            ref = ref[:, :, :k, :k] if corner == "tl" else ref[:, :, -k:, -k:]
+            e = float((got - ref).norm() / ref.norm())
+            assert e <= tol, f"{what}: images {imgs}, corner {corner}: rel L2 {e:.3e} > {tol:.1e}"
+
+
+def _convT_corner_crops(y, x, w, bias, stride, prep=None, c=8, tol=3e-6, what="convT"):
+    """As `_conv_corner_crops` for the transposed convolution x (B,Cin,H,W) -> y (B,Cout,sH,sW)."""
+    B, Hs, Ws = x.shape[0], x.shape[2], x.shape[3]
+    k = stride * (c - 2)                        # output pixels that only see the crop's inputs
+    for imgs in (slice(0, 2), slice(B - 1, B)):
+        for corner in ("tl", "br"):
+            xs = x[imgs, :, :c, :c] if corner == "tl" else x[imgs, :, Hs - c:, Ws - c:]
+            xs = xs.cpu().double()
+            ref = O.convT5x5(prep(xs) if prep else xs, w.cpu(), None if bias is None else bias.cpu(), stride)
+            got = (y[imgs, :, :k, :k] if corner == "tl" else y[imgs, :, -k:, -k:]).cpu().double()
+            ref = ref[:, :, :k, :k] if corner == "tl" else ref[:, :, -k:, -k:]
+            e = float((got - ref).norm() / ref.norm())
+            assert e <= tol, f"{what}: images {imgs}, corner {corner}: rel L2 {e:.3e} > {tol:.1e}"
+
+
 @pytest.mark.parametrize("Cin,Cout,Hs,stride", CONV_LAYERS)
 def test_full_size_conv_adjoints(H, conv_arith, Cin, Cout, Hs, stride):
     """BASELINE batch (128): <conv(x,w), g> == <x, dgrad(g,w)> == <w, wgrad(x,g)> (the three
-    kernels are transposes of one bilinear map), and the forward is linear in x."""
+    kernels are transposes of one bilinear map), the forward is linear in x, and corner crops of the forward and
+    of the data gradient agree with the fp64 oracle (the launches the headline benchmark times)."""
     B = 128
     gen = torch.Generator(device="cuda").manual_seed(50)
     x = torch.randn(B, Cin, Hs, Hs, device="cuda", generator=gen)
@@ -300,7 +335,8 @@ def test_full_size_conv_adjoints(H, conv_arith, Cin, Cout, Hs, stride):
     y = H.conv5x5_fwd(x, w, None, stride)
     g = torch.randn(y.shape, device="cuda", generator=gen)
     s_fwd = _dot(y, g)
-    s_dgrad = _dot(x, H.convT5x5_fwd(g, w, None, stride))
+    gx = H.convT5x5_fwd(g, w, None, stride)
+    s_dgrad = _dot(x, gx)
     s_wgrad = _dot(w, H.conv5x5_wgrad(x, g, stride))
     scale = float(y.double().norm() * g.double().norm())
     assert abs(s_fwd - s_dgrad) <= 2e-6 * scale, (s_fwd, s_dgrad, scale)
@@ -308,10 +344,14 @@ def test_full_size_conv_adjoints(H, conv_arith, Cin, Cout, Hs, stride):
     x2 = torch.randn(x.shape, device="cuda", generator=gen)
     lin = H.conv5x5_fwd(0.5 * x + x2, w, None, stride) - (0.5 * y + H.conv5x5_fwd(x2, w, None, stride))
     assert float(lin.double().norm()) <= 3e-6 * float(y.double().norm()) * 3
+    _conv_corner_crops(y, x, w, None, stride, tol=CONV_TOL, what="conv fwd B=128")
+    # the data gradient is the transposed convolution of g with the same filter (w read as (Cin', Cout') = (Cout, Cin))
+    _convT_corner_crops(gx, g, w, None, stride, tol=CONV_TOL, what="conv dgrad B=128")
 
 
 @pytest.mark.parametrize("Cin,Cout,Hs,stride", CONVT_LAYERS)
 def test_full_size_convT_adjoints(H, conv_arith, Cin, Cout, Hs, stride):
+    """As above for the decoder's transposed convolutions (+ bias added once per output channel)."""
     B = 128
     gen = torch.Generator(device="cuda").manual_seed(51)
     x = torch.randn(B, Cin, Hs, Hs, device="cuda", generator=gen)
@@ -320,13 +360,17 @@ def test_full_size_convT_adjoints(H, conv_arith, Cin, Cout, Hs, stride):
     y0 = H.convT5x5_fwd(x, w, None, stride)
     g = torch.randn(y0.shape, device="cuda", generator=gen)
     s_fwd = _dot(y0, g)
-    s_dgrad = _dot(x, H.conv5x5_fwd(g, w, None, stride))
+    gx = H.conv5x5_fwd(g, w, None, stride)
+    s_dgrad = _dot(x, gx)
     s_wgrad = _dot(w, H.conv5x5_wgrad(g, x, stride))
     scale = float(y0.double().norm() * g.double().norm())
     assert abs(s_fwd - s_dgrad) <= 2e-6 * scale
     assert abs(s_fwd - s_wgrad) <= 2e-6 * scale
     yb = H.convT5x5_fwd(x, w, b, stride)                 # bias is added once per output channel
     assert float(((yb - y0) - b.view(1, -1, 1, 1)).abs().max()) <= 1e-5 * float(y0.abs().max())
+    _convT_corner_crops(yb, x, w, b, stride, tol=CONV_TOL, what="convT fwd B=128")
+    # data gradient of a transposed convolution = the convolution of g with the same filter read as (Cout', Cin')
+    _conv_corner_crops(gx, g, w, None, stride, tol=CONV_TOL, what="convT dgrad B=128")
 
 
 @pytest.mark.parametrize("shape", [(128, 32, 64, 64), (128, 256, 8, 8), (128, 16384)])
@@ -667,6 +711,55 @@ def test_conv_input_affine_and_output_stats(H, B, Cin, Cout, Hs, Ws, transposed,
         _, gw_ref = O.conv5x5_grads(xa, w, gy, 2)
         gw = H.conv5x5_wgrad(x.cuda(), gy.cuda(), 2, in_affine=(scale.cuda(), shift.cuda(), code))
     assert_close(gw, gw_ref, CONV_TOL, "wgrad with input affine")
+
+
+@pytest.mark.parametrize("B", [128, 96])
+@pytest.mark.parametrize("transposed,Cin,Cout,Hs,act", [(False, 128, 256, 32, "lrelu"), (True, 256, 128, 16, "relu"),
+                                                        (False, 32, 128, 64, "lrelu"), (True, 256, 256, 8, "relu")])
+def test_stats_epilogue_at_the_benchmarked_sizes(H, B, transposed, Cin, Cout, Hs, act):
+    """The launches the headline benchmark times, with everything the trainer asks of them: the producer's BatchNorm +
+    activation applied on load AND the statistics epilogue -- which the K-split launches of small batches drop
+    (conv_ring.hip: a grid below 192 workgroups splits K and falls back to a statistics pass), so only batches >= 96
+    (dominant layer convs.6 128->256 @32->16, ring variant 0) / >= 48 (deconv2 256->128 @16->32, variant 3) reach it.
+    Checked: the slots exist, reduce to the sums of the kernel's own output (1e-5), the output agrees with the fp64
+    oracle on corner crops (3e-6), and vg_bn_finalize_stats turns the slots into the batch statistics of the output."""
+    code = {"relu": 1, "lrelu": 2}[act]
+    gen = torch.Generator(device="cuda").manual_seed(72)
+    x = torch.randn(B, Cin, Hs, Hs, device="cuda", generator=gen)
+    scale = 0.5 + torch.rand(Cin, device="cuda", generator=gen)
+    shift = torch.randn(Cin, device="cuda", generator=gen)
+    w = 0.05 * torch.randn(*((Cin, Cout, 5, 5) if transposed else (Cout, Cin, 5, 5)), device="cuda", generator=gen)
+    bias = torch.randn(Cout, device="cuda", generator=gen)
+    conv = H.convT5x5_fwd if transposed else H.conv5x5_fwd
+    y, stats = conv(x, w, bias, 2, in_affine=(scale, shift, code), want_stats=True)
+    assert H.conv_fusable(transposed, Cin, Cout, 2)
+    lib = __import__("disentangle_mlp_amd._lib", fromlist=["load"]).load()
+    wsb = (lib.vg_convT5x5_fwd_bf16split_workspace_bytes if transposed else lib.vg_conv5x5_fwd_bf16split_workspace_bytes)(
+        B, Cin, Hs, Hs, Cout, 2)
+    if wsb == 0:                                   # not K-split: the epilogue must have run
+        assert stats is not None and stats.numel() % (2 * Cout) == 0
+    if stats is not None:
+        st = stats.view(-1, Cout, 2).double().sum(0)
+        yd = y.double()
+        assert_close(st[:, 0].cpu(), yd.sum((0, 2, 3)).cpu(), 1e-5, "statistics: sum y")
+        assert_close(st[:, 1].cpu(), (yd * yd).sum((0, 2, 3)).cpu(), 1e-5, "statistics: sum y^2")
+        gamma = 1 + 0.1 * torch.randn(Cout, device="cuda", generator=gen)
+        beta = 0.1 * torch.randn(Cout, device="cuda", generator=gen)
+        rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+        n = y.numel() // Cout
+        mean, invstd, sc2, sh2 = H.bn_finalize_stats(stats, n, gamma, beta, rm, rv, 1e-5, 0.1)
+        m_ref, v_ref = yd.mean((0, 2, 3)), yd.var((0, 2, 3), unbiased=False)
+        assert_close(mean.cpu(), m_ref.cpu(), 1e-5, "batch mean from the slots")
+        assert_close(invstd.cpu(), (v_ref + 1e-5).rsqrt().cpu(), 1e-5, "1/std from the slots")
+        assert_close(rm.cpu(), (0.1 * m_ref).cpu(), 1e-5, "running mean")
+        assert_close(rv.cpu(), (0.9 + 0.1 * v_ref * n / (n - 1)).cpu(), 1e-5, "running var")
+        assert_close(sc2.cpu(), (gamma.double() * (v_ref + 1e-5).rsqrt()).cpu(), 1e-5, "scale")
+
+    def prep(t):
+        a = t * scale.double().cpu().view(1, -1, 1, 1) + shift.double().cpu().view(1, -1, 1, 1)
+        return a.clamp(min=0) if act == "relu" else torch.where(a > 0, a, 0.2 * a)
+    (_convT_corner_crops if transposed else _conv_corner_crops)(y, x, w, bias, 2, prep=prep, tol=CONV_TOL,
+                                                                what=f"B={B} fused launch")
 
 
 def test_bn_coefficients_from_stats_and_from_pass(H):

@@ -411,24 +411,37 @@ def test_gradients_at_trained_weights_vs_oracle(T):
 
 def test_short_trajectory_tracks_the_oracle(T):
     """scripts/trajectory_vs_oracle.py as a test: both engines run 6 iterations on the same inputs (B = 16).
-    After Adam's first sign-like step the two are chaotic twins (the reference moves its own kld by 0.5 % with the
-    thread count), so the bounds are on trends: D(x) within 0.02 absolute, reconstruction error within 8 % at every
-    iteration; the first iteration's phase-1 numbers at 2e-5 and its KL at 3 % (conftest.LOSS_TOL).  The
-    beta-weighted KL of LATER iterations -- 25 x a sum of exp(logvar) right after sign-like updates of every encoder
-    weight -- is not bounded: the reference's own evaluations disagree there by more than any useful tolerance
-    (scripts/diag_traj.py on the GPU box's host: iteration 1: 275 559 / 360 752 / 314 561 for fp32 16 threads / fp32
-    1 thread / fp64; iteration 2: 5.2e6 / 2.2e6 / 5.8e6), and this engine's four arithmetic / fusion variants scatter
-    over the same band (1.3e5 .. 2.6e5; 4.3e6 .. 1.6e7).  It is only required to stay finite."""
+    After Adam's first sign-like step the two are chaotic twins (one LeakyReLU unit of D's 16 x 2048 Dis_l features
+    on the other side of zero moves every gradient behind it by 0.8 / sqrt(32768) = 4.4e-3 -- measured between the
+    reference's own fp32 and fp64 runs, scripts/diag_kl_signs.py -- and the next sign-like step turns that into tens of
+    thousands of weights stepping the other way), so the bounds are on trends: D(x) within 0.02 absolute,
+    reconstruction error within 8 % at every iteration; the first iteration's phase-1 numbers at 2e-5 and its KL at 3 %
+    (conftest.LOSS_TOL).  The beta-weighted KL of iterations 1 and 2 -- 25 x a sum of exp(logvar) right after
+    sign-like updates of every encoder weight -- is bounded by the reference itself: the test evaluates the
+    reference's trajectory three ways (fp32 on 16 threads, fp32 on 1 thread, fp64: they disagree by up to 2.6x there)
+    and requires the build's KL inside [min / 1.5, 1.5 max] of those three; later iterations: finite and positive."""
     n_it, batch = 6, 16
-    torch.set_num_threads(16)
     g = torch.Generator().manual_seed(7)
     base = torch.randn(4 * batch, 3, 8, 8, generator=g)
     data = torch.tanh(torch.nn.functional.interpolate(base, size=64, mode="bilinear"))
+    rnd = [[torch.randn(batch, 128, generator=g) for _ in range(3)] for _ in range(n_it)]
+
+    def oracle_kls(n, threads, dtype):
+        """beta*KL of the reference's first n iterations, evaluated with `threads` threads in `dtype`."""
+        torch.set_num_threads(threads)
+        eg, d, oeg, od = osteps.build_nets(dtype=dtype)
+        try:
+            return [osteps.betavaegan_step(eg, d, oeg, od, data[(it % 4) * batch:(it % 4 + 1) * batch].to(dtype),
+                                           *[t.to(dtype) for t in rnd[it]], beta=25.0)["kld"] for it in range(n)]
+        finally:
+            torch.set_num_threads(16)
+    kl_refs = [oracle_kls(3, 1, torch.float32), oracle_kls(3, 16, torch.float64)]
+    torch.set_num_threads(16)
     tr = T.BetaVAEGANTrainer(beta=25.0)
     eg, d, oeg, od = osteps.build_nets()
     for it in range(n_it):
         x = data[(it % 4) * batch:(it % 4 + 1) * batch]
-        no, e2, e3 = (torch.randn(batch, 128, generator=g) for _ in range(3))
+        no, e2, e3 = rnd[it]
         out = tr.step(x.cuda(), no.cuda(), e2.cuda(), e3.cuda())
         ref = osteps.betavaegan_step(eg, d, oeg, od, x, no, e2, e3, beta=25.0)
         if it == 0:
@@ -437,7 +450,13 @@ def test_short_trajectory_tracks_the_oracle(T):
         assert close(float(out["mse_enc"]), ref["mse_enc"], 0.08), (it, float(out["mse_enc"]), ref["mse_enc"])
         assert close(float(out["mse_dec"]), ref["mse_dec"], 0.08), (it, float(out["mse_dec"]), ref["mse_dec"])
         kl = float(out["kld"])
-        assert (abs(kl / ref["kld"] - 1) <= 0.03) if it == 0 else (math.isfinite(kl) and kl > 0), (it, kl, ref["kld"])
+        if it == 0:
+            assert abs(kl / ref["kld"] - 1) <= 0.03, (it, kl, ref["kld"])
+        elif it <= 2:
+            three = [ref["kld"], kl_refs[0][it], kl_refs[1][it]]
+            assert min(three) / 1.5 <= kl <= 1.5 * max(three), (it, kl, three)
+        else:
+            assert math.isfinite(kl) and kl > 0, (it, kl)
 
 
 def test_train_epoch_on_device_loader_vs_oracle_loop(T):
@@ -471,14 +490,18 @@ def test_train_epoch_on_device_loader_vs_oracle_loop(T):
     assert close(dx, dx_sum / 10, 2e-3), (dx, dx_sum / 10)
 
 
-def test_fused_conv_bn_equals_two_pass_batchnorm(T):
+@pytest.mark.parametrize("batch", [8, 128])
+def test_fused_conv_bn_equals_two_pass_batchnorm(T, batch):
     """Conv <-> BatchNorm fusion (model.FUSE_CONV_BN: statistics from the convolution epilogue, normalise + activation
     applied by the consumer while it loads) against the unfused path (every BatchNorm its own statistics and
     normalise passes): same losses (1e-5), same gradients (1e-3 relative L2 per tensor: only the summation order of
     the statistics differs -- a batch mean moves by ~1e-7 relative -- but at B = 8 one ReLU unit whose pre-activation
-    rounds to the other side of zero moves a gradient tensor by up to ~1e-3), same BatchNorm buffers, lr = 0."""
+    rounds to the other side of zero moves a gradient tensor by up to ~1e-3), same BatchNorm buffers, lr = 0.
+    Batch 8: every ring-kernel launch is K-split and takes the fallback statistics pass; batch 128 (the benchmark's):
+    the statistics come from the ring kernels' own epilogue (the two-pass path it is compared with is pinned to the
+    oracle at small batches)."""
     from disentangle_mlp_amd import model as M
-    b = {k: v.cuda() for k, v in osteps.synthetic_batch(8).items()}
+    b = {k: v.cuda() for k, v in osteps.synthetic_batch(batch).items()}
     res = {}
     prev = M.FUSE_CONV_BN
     try:
@@ -492,13 +515,19 @@ def test_fused_conv_bn_equals_two_pass_batchnorm(T):
                           {k: v.detach().double().clone() for n in (tr.netEG, tr.netD) for k, v in n.state_dict().items() if "running" in k or "num_batches" in k})
     finally:
         M.FUSE_CONV_BN = prev
+    # what the epilogue feeds directly: the losses and every BatchNorm's running statistics
     for k, v in res[False][0].items():
         assert close(res[True][0][k], v, 1e-5, 1e-7), (k, res[True][0][k], v)
+    for k, r in res[False][2].items():
+        assert float((res[True][2][k] - r).abs().max()) <= 1e-5 * max(float(r.abs().max()), 1.0), k
+    # gradients.  Batch 8: 1e-3.  Batch 128: the suite's stated per-tensor bound 3e-3 -- the two
+    # paths differ by ~1e-6 in D's Dis_l features after four layers, so over the three D passes of 128 x 2048 LeakyReLU
+    # units about one unit in two runs lands on the other side of zero, and ONE such unit moves every gradient behind
+    # it by 0.8 / sqrt(128 * 2048) = 1.6e-3 (measured on the first run of this case: 1.67e-3 on every EG tensor).
+    grad_tol = 1e-3 if batch == 8 else 3e-3
     for ph, key in (("D", "d"), ("EG2", "eg"), ("EG3", "eg")):
         for k, r in res[False][1][ph].items():
             if float(r.norm()) == 0.0 or k in BN_SHADOWED[key]:      # shadowed biases: rounding noise on both sides
                 continue
             e = float((res[True][1][ph][k] - r).norm() / r.norm())
-            assert e <= 1e-3, (ph, k, e)
-    for k, r in res[False][2].items():
-        assert float((res[True][2][k] - r).abs().max()) <= 1e-5 * max(float(r.abs().max()), 1.0), k
+            assert e <= grad_tol, (ph, k, e)
