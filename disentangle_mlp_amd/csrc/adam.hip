@@ -34,8 +34,29 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
   p = p - step_size * (m / denom);
 }
 
+// One thread: the scalars of an optimizer step whose step count lives on the device (a step captured in a HIP graph
+// cannot take them as kernel arguments: they change from replay to replay).  `advance`: the device counter is advanced
+// by one and used (captured steps); otherwise `step_host` is used and, when there is a device counter, stored in it (an
+// eager step between replays keeps the counter current).  Both ways the bias corrections are formed here, in double,
+// from the same expression -- an eager step and a replayed one give the same bits.
+__global__ void adam_prepare_kernel(double step_host, double* __restrict__ step_dev, int advance, double lr, double beta1,
+                                    double beta2, float* __restrict__ scalars) {
+  double step = step_host;
+  if (advance) step = step_dev[0] + 1.0;
+  if (step_dev) step_dev[0] = step;
+  const double bc1 = 1.0 - pow(beta1, step);
+  const double bc2 = 1.0 - pow(beta2, step);
+  scalars[0] = (float)(lr / bc1);       // step_size
+  scalars[1] = (float)sqrt(bc2);        // bias_correction2_sqrt
+}
+
+template <bool DEV>
 __global__ __launch_bounds__(ANT) void adam_multi_kernel(AdamPack A, float omb1, float b2, float omb2, float step_size,
-                                                        float bc2s, float eps) {
+                                                        float bc2s, float eps, const float* __restrict__ scalars) {
+  if constexpr (DEV) {
+    step_size = scalars[0];
+    bc2s = scalars[1];
+  }
   int t = 0;
   while (t + 1 < A.count && blockIdx.x >= A.first_block[t + 1]) ++t;
   const unsigned long long n = A.n[t];
@@ -70,14 +91,10 @@ __global__ __launch_bounds__(ANT) void adam_multi_kernel(AdamPack A, float omb1,
 
 }  // namespace
 
-extern "C" int vg_adam_step(const VgAdamTensor* tensors, int count, double lr, double beta1, double beta2, double eps,
-                            double bias_correction1, double bias_correction2_sqrt, void* stream) {
-  if (count < 0 || (count > 0 && !tensors) || !(bias_correction1 > 0.0) || !(bias_correction2_sqrt > 0.0))
-    return VG_ERR_BAD_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  // scalars are formed in double and rounded once, as torch does with its Python-side hyper-parameters
-  const float step_size = (float)(lr / bias_correction1);
-  const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2), bc2s = (float)bias_correction2_sqrt;
+namespace {
+int adam_launch(const VgAdamTensor* tensors, int count, double beta1, double beta2, double eps, float step_size, float bc2s,
+                const float* scalars, hipStream_t st) {
+  const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
   int i = 0;
   while (i < count) {
     AdamPack A;
@@ -96,9 +113,40 @@ extern "C" int vg_adam_step(const VgAdamTensor* tensors, int count, double lr, d
     }
     if (A.count == 0) break;
     A.first_block[A.count] = blocks;
-    hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(ANT), 0, st, A, omb1, (float)beta2, omb2, step_size, bc2s,
-                       (float)eps);
+    if (scalars)
+      hipLaunchKernelGGL(adam_multi_kernel<true>, dim3(blocks), dim3(ANT), 0, st, A, omb1, (float)beta2, omb2, 0.f, 0.f,
+                         (float)eps, scalars);
+    else
+      hipLaunchKernelGGL(adam_multi_kernel<false>, dim3(blocks), dim3(ANT), 0, st, A, omb1, (float)beta2, omb2, step_size,
+                         bc2s, (float)eps, (const float*)nullptr);
     VG_CHECK_LAUNCH();
   }
   return 0;
+}
+}  // namespace
+
+extern "C" int vg_adam_step(const VgAdamTensor* tensors, int count, double lr, double beta1, double beta2, double eps,
+                            double bias_correction1, double bias_correction2_sqrt, void* stream) {
+  if (count < 0 || (count > 0 && !tensors) || !(bias_correction1 > 0.0) || !(bias_correction2_sqrt > 0.0))
+    return VG_ERR_BAD_ARG;
+  // scalars are formed in double and rounded once, as torch does with its Python-side hyper-parameters
+  return adam_launch(tensors, count, beta1, beta2, eps, (float)(lr / bias_correction1), (float)bias_correction2_sqrt,
+                     nullptr, (hipStream_t)stream);
+}
+
+extern "C" int vg_adam_prepare(double step, double* step_dev, int advance_device_counter, double lr, double beta1,
+                               double beta2, float* scalars, void* stream) {
+  if (!scalars || (advance_device_counter ? !step_dev : !(step >= 1.0)) || !(beta1 >= 0.0 && beta1 < 1.0) ||
+      !(beta2 >= 0.0 && beta2 < 1.0))
+    return VG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, step_dev,
+                     advance_device_counter ? 1 : 0, lr, beta1, beta2, scalars);
+  VG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vg_adam_step_dev(const VgAdamTensor* tensors, int count, double beta1, double beta2, double eps,
+                                const float* scalars, void* stream) {
+  if (count < 0 || (count > 0 && !tensors) || !scalars) return VG_ERR_BAD_ARG;
+  return adam_launch(tensors, count, beta1, beta2, eps, 0.f, 0.f, scalars, (hipStream_t)stream);
 }

@@ -138,6 +138,11 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
 #endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: keeps the DMA's LDS base in SGPRs
+#ifndef VG_RING_STAGGER
+#define VG_RING_STAGGER 0
+#endif
+  constexpr bool STG = VG_RING_STAGGER != 0;
+  const bool early = STG && wid >= 4;                             // wave-uniform: meets each barrier half a body late
   const int kb = lane >> 5, l32 = lane & 31;
   const int wc = wid % C::WC, wp = wid / C::WC;
   // XCD-aware placement (conv_igemm.hip): the cout tiles of one pixel tile share an XCD
@@ -372,12 +377,56 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
       const bool ld = (MODE == R_FWD) ? (s == 0 || s == 13) : (s == 0);
       const bool wr = (MODE == R_FWD) ? (s == 4 || s == 17) : (s == LW);
       const int wbuf = (MODE == R_FWD) ? (s == 4 ? BUFU : 0) : pnxt;
-      if (!(abl & 2)) __builtin_amdgcn_s_barrier();       // B_k: slot (k+1)%3 and the patch writes of body k-1 are visible
+      // B_k: slot (k+1)%3 and the patch writes of body k-1 are visible.  Staggered build: the second-dispatched half of
+      // the wavefronts (4-7: the SIMD partners of 0-3) meets the same barrier in the MIDDLE of its body, see below.
+      if (!(abl & 2) && !early) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       const int nslot = (slot == NSLOT - 1) ? 0 : slot + 1;
       const int so = nslot * SLOTU;
       // the next step's patch offset (the last body reads step 0 of the next chunk)
       const int bo = (s + 1 < NSTEP) ? patch_off(s + 1, pcur) : patch_off(0, pnxt);
+      if constexpr (STG) {
+        // Stagger (MI355X_MICROARCH.md, "Two waves per SIMD", item 9): a body is [H1: the first half of the step's
+        // MFMAs, nothing else][H2: the second half + EVERYTHING that touches memory -- filter DMA, staging loads, the
+        // next step's fragment reads, patch writes].  Wavefronts 0-3 pass the step's barrier before H1, wavefronts 4-7
+        // between H1 and H2: every memory operation of body k still falls between barriers k and k+1 for all eight
+        // (the hazard analysis of the file header holds unchanged), but the two wavefronts of a SIMD are half a body
+        // apart, so one of them has MFMAs to issue while the other drains its waits and sits at the barrier.
+        // Accumulation order per output is unchanged: results are bit-identical to the lockstep build.
+        constexpr int H1N = NMF / 2, H2N = NMF - H1N;
+        constexpr int RPM = (NRD + H2N - 1) / H2N;           // fragment reads per MFMA of H2
+#pragma unroll
+        for (int i = 0; i < H1N; ++i)
+          if (!(abl & 64)) mfma_one(cur, i);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(abl & 2) && early) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = H1N; i < NMF; ++i) {
+          const int j = i - H1N;
+          if (!(abl & 64)) mfma_one(cur, i);
+          if (j == 0) {
+            if (!(abl & 1)) dma_next(slot);                // step k+3 into the slot read during body k-1
+            if (ld && !(abl & 4)) {
+              if constexpr (MODE == R_FWD) stage_load(ch * 16 + (s == 0 ? 8 : 16));
+              else stage_load((ch + 1) * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int r = 0; r < RPM; ++r)
+            if (j * RPM + r < NRD && !(abl & ((j * RPM + r < FC * NP) ? 32 : 16))) read_one(nxt, j * RPM + r, so, bo);
+          __builtin_amdgcn_sched_barrier(0);
+          if (wr && !(abl & 4) && j < NQ) {
+            split_unit(j, wbuf);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (wr && !(abl & 4)) {
+#pragma unroll
+          for (int q = H2N; q < NQ; ++q) split_unit(q, wbuf);
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < NMF; ++i) {
         if (!(abl & 64)) mfma_one(cur, i);
@@ -401,9 +450,19 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
       }
 #pragma unroll
       for (int j = NMF / RS; j < NRD; ++j) read_one(nxt, j, so, bo);     // reads the MFMA count left over
+      if constexpr ((abl & 256) != 0) {
+        // timing experiment: what a v_mfma_f32_16x16x32_bf16 build would read on top -- (FC + FP) * 2 * 2 operand
+        // registers per step instead of (FC + FP) * 3: one more read per fragment row / column (results discarded)
+#pragma unroll
+        for (int j = 0; j < FC + FP; ++j) {
+          f32x4 d = (j < FC) ? lds[base_a[j] + so + TN] : lds[base_b[j - FC] + bo + 1];
+          asm volatile("" ::"v"(d));
+        }
+      }
       if (wr && !(abl & 4)) {
 #pragma unroll
         for (int q = NMF - NMF / 2; q < NQ; ++q) split_unit(q, wbuf);
+      }
       }
       // DMA(k+2) has landed (DMA(k+3), and a staging event's loads for two bodies, stay in flight);
       // this wavefront's reads of step k+1 and its patch writes are done

@@ -146,9 +146,11 @@ __global__ __launch_bounds__(NT) void sum_finalize_kernel(const double* __restri
   if (threadIdx.x == 0) out[0] = (float)(scale * t);
 }
 
-__global__ __launch_bounds__(NT) void bce_kernel(const float* __restrict__ p, float target, float* __restrict__ loss,
+__global__ __launch_bounds__(NT) void bce_kernel(const float* __restrict__ p, float target,
+                                                 const float* __restrict__ target_dev, float* __restrict__ loss,
                                                  float* __restrict__ gp, int B, float inv_div, float gscale) {
   __shared__ double red[NT / 64];
+  if (target_dev) target = target_dev[0];       // a label that changes between replays of a captured iteration
   double s = 0.0;
   for (int i = threadIdx.x; i < B; i += NT) {
     const float v = p[i];
@@ -246,7 +248,16 @@ extern "C" int vg_sqdiff_loss(const float* a, const float* b, float* loss, float
 extern "C" int vg_bce_loss(const float* p, float target, float* loss, float* gp, int B, float divisor, float gscale,
                            void* stream) {
   if (!p || B <= 0 || !(divisor > 0.f)) return VG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, p, target, loss, gp, B, 1.f / divisor,
+  hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, p, target, (const float*)nullptr, loss, gp, B,
+                     1.f / divisor, gscale);
+  VG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vg_bce_loss_dev(const float* p, const float* target_dev, float* loss, float* gp, int B, float divisor,
+                               float gscale, void* stream) {
+  if (!p || !target_dev || B <= 0 || !(divisor > 0.f)) return VG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, p, 0.f, target_dev, loss, gp, B, 1.f / divisor,
                      gscale);
   VG_CHECK_LAUNCH();
   return 0;

@@ -419,4 +419,7 @@ def reconstruction_loss(recon_x, x):
 
 
 def bce_loss(p, label_value, divisor=None):
-    return BCELossFn.apply(p.contiguous(), float(label_value), divisor)
+    """``label_value``: a float, or a one-element device tensor (see ops.bce_loss)."""
+    if not isinstance(label_value, torch.Tensor):
+        label_value = float(label_value)
+    return BCELossFn.apply(p.contiguous(), label_value, divisor)

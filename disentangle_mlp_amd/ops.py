@@ -617,13 +617,23 @@ def sqdiff_loss(a, b, scale, gscale=1.0, want_grad=True):
 
 
 def bce_loss(p, target, divisor=None, gscale=1.0, want_grad=True):
+    """``target``: a Python float, or a one-element fp32 DEVICE tensor (a label that changes between replays of a
+    captured iteration: the kernel reads it from memory)."""
     lib = _lib.load()
     _req(p, "p")
     B = p.numel()
     loss = torch.empty((), dtype=torch.float32, device=p.device)
     gp = torch.empty_like(p) if want_grad else None
-    check(lib.vg_bce_loss(p.data_ptr(), float(target), loss.data_ptr(), _ptr(gp), B,
-                          float(divisor if divisor is not None else B), float(gscale), _stream()), "vg_bce_loss")
+    div = float(divisor if divisor is not None else B)
+    if isinstance(target, torch.Tensor):
+        _req(target, "target")
+        if target.numel() != 1:
+            raise RuntimeError("bce_loss: a device label is one fp32 value")
+        check(lib.vg_bce_loss_dev(p.data_ptr(), target.data_ptr(), loss.data_ptr(), _ptr(gp), B, div, float(gscale),
+                                  _stream()), "vg_bce_loss_dev")
+    else:
+        check(lib.vg_bce_loss(p.data_ptr(), float(target), loss.data_ptr(), _ptr(gp), B, div, float(gscale), _stream()),
+              "vg_bce_loss")
     return loss, gp
 
 

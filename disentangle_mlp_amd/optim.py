@@ -24,9 +24,21 @@ class _AdamTensor(ctypes.Structure):
 
 
 class HipAdam(optim.Adam):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+    """``capturable=True``: the step's scalars (lr / bias_correction1, sqrt(bias_correction2)) are formed on the DEVICE
+    by ``vg_adam_prepare`` -- from the host's step count in an eager step, from a device counter in a step that is being
+    captured in a HIP graph (kernel arguments are frozen at capture, the step count is not) -- so a whole iteration
+    including its optimizer steps can be captured and replayed (trainer.BetaVAEGANTrainer(graph=True)), and an eager step
+    and a replayed one give the same bits.  The ``state_dict`` stays torch.optim.Adam's (``step`` as a CPU tensor): the
+    host mirrors the device counter (`prepare_capture` / `replayed`)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, capturable=False):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad,
                          foreach=False, fused=False, capturable=False)
+        self.device_scalars = bool(capturable)
+        self._dev = {}            # group index -> (device step counter float64[1], scalars float32[2])
+        self._captured = []       # per captured step() call: the parameters it stepped (host bookkeeping of a replay)
+        self._debt = 0            # replays whose host-side step counts have not been added yet (flushed lazily)
+        self.register_state_dict_pre_hook(lambda opt: opt._flush_replays())
 
     def _native_ok(self, group):
         if group["weight_decay"] != 0 or group["amsgrad"] or group.get("maximize", False) \
@@ -41,13 +53,60 @@ class HipAdam(optim.Adam):
                 return False
         return True
 
+    # ---- HIP-graph support -------------------------------------------------------------------------------
+    def _device_state(self, gi, device):
+        d = self._dev.get(gi)
+        if d is None:
+            d = self._dev[gi] = (torch.zeros(1, dtype=torch.float64, device=device),
+                                 torch.zeros(2, dtype=torch.float32, device=device))
+        return d
+
+    def _flush_replays(self):
+        """Add the step counts of the replays made since the last flush to the host-side ``state[p]["step"]``."""
+        if self._debt:
+            for params in self._captured:
+                for p in params:
+                    self.state[p]["step"] += self._debt
+            self._debt = 0
+
+    def prepare_capture(self):
+        """Before a capture that contains step() calls: every parameter of a group must be at the same step count (the
+        captured kernels share one device counter per group), which the device counter is set to."""
+        if not self.device_scalars:
+            raise RuntimeError("HipAdam: construct with capturable=True to capture its step in a HIP graph")
+        self._flush_replays()
+        self._captured = []
+        for gi, group in enumerate(self.param_groups):
+            steps = {float(self.state[p]["step"]) for p in group["params"] if len(self.state[p])}
+            unborn = [p for p in group["params"] if not len(self.state[p])]
+            if len(steps) > 1 or (steps and unborn):
+                raise RuntimeError("HipAdam.prepare_capture: parameters of one group are at different step counts")
+            dev = group["params"][0].device
+            self._device_state(gi, dev)[0].fill_(steps.pop() if steps else 0.0)
+
+    def replayed(self, times=1):
+        """A captured iteration was replayed: the device counters advanced inside the graph, the host's follow (lazily)."""
+        self._debt += times
+
+    def load_state_dict(self, state_dict):
+        self._debt, self._captured = 0, []
+        return super().load_state_dict(state_dict)
+
     @torch.no_grad()
     def step(self, closure=None):
         if closure is not None or not all(self._native_ok(g) for g in self.param_groups):
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("HipAdam: this configuration takes torch's step, which cannot be captured here")
+            self._flush_replays()
             return super().step(closure)
         lib = _lib.load()
         stream = torch.cuda.current_stream().cuda_stream
-        for group in self.param_groups:
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing and not self.device_scalars:
+            raise RuntimeError("HipAdam: construct with capturable=True to capture its step in a HIP graph")
+        if not capturing:
+            self._flush_replays()
+        for gi, group in enumerate(self.param_groups):
             beta1, beta2 = group["betas"]
             by_step = {}
             for p in group["params"]:
@@ -65,10 +124,22 @@ class HipAdam(optim.Adam):
                 if not (m.is_contiguous() and v.is_contiguous()):
                     raise RuntimeError("HipAdam: optimizer state must be contiguous")
                 by_step.setdefault(float(st["step"]), []).append((p, p.grad, m, v))
+            if capturing and len(by_step) > 1:
+                raise RuntimeError("HipAdam: a captured step needs every parameter of a group at the same step count")
             for step, items in by_step.items():
                 arr = (_AdamTensor * len(items))()
                 for i, (p, g, m, v) in enumerate(items):
                     arr[i] = _AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel())
+                if self.device_scalars:
+                    step_dev, scalars = self._device_state(gi, items[0][0].device)
+                    # an eager step also stores its count in the device counter: replays may follow it
+                    check(lib.vg_adam_prepare(float(step), step_dev.data_ptr(), 1 if capturing else 0, float(group["lr"]),
+                                              float(beta1), float(beta2), scalars.data_ptr(), stream), "vg_adam_prepare")
+                    check(lib.vg_adam_step_dev(arr, len(items), float(beta1), float(beta2), float(group["eps"]),
+                                               scalars.data_ptr(), stream), "vg_adam_step_dev")
+                    if capturing:
+                        self._captured.append([it[0] for it in items])
+                    continue
                 bc1 = 1.0 - beta1 ** step
                 bc2_sqrt = math.sqrt(1.0 - beta2 ** step)
                 check(lib.vg_adam_step(arr, len(items), float(group["lr"]), float(beta1), float(beta2), float(group["eps"]),

@@ -194,13 +194,11 @@ def _backward(losses):
 
 def _make_adam(params, lr, fused, capturable=False):
     """Adam with the reference's defaults (new_betavaegan.py:49-50).  On the GPU the step runs on the
-    hand-written kernel (optim.HipAdam, a torch.optim.Adam subclass: identical state_dict); ``capturable``
-    -- step counters on the device so that a whole iteration can be captured in a HIP graph -- and CPU
-    construction use torch's own implementations."""
-    if fused and not capturable:
-        return HipAdam(params, lr=lr)
+    hand-written kernel (optim.HipAdam, a torch.optim.Adam subclass: identical state_dict); ``capturable``:
+    its scalars are formed on the device so that a whole iteration can be captured in a HIP graph.  CPU
+    construction uses torch's own implementation."""
     if fused:
-        return optim.Adam(params, lr=lr, fused=True, capturable=True)
+        return HipAdam(params, lr=lr, capturable=capturable)
     return optim.Adam(params, lr=lr, capturable=capturable)
 
 
@@ -251,14 +249,92 @@ def _loader_global_batch(loader, local_batch, world):
     return int(gb) if gb else int(local_batch) * world
 
 
+GRAPH_DEFAULT = __import__("os").environ.get("VG_GRAPH", "1") != "0"     # 0: trainers never capture (every step eager)
+GRAPH_WARM_STEPS = 2      # eager iterations of a shape before it is captured (workspaces, packs, GEMM plans exist then)
+
+
+class _CapturedIteration:
+    """One training iteration captured in a HIP graph (torch.cuda.CUDAGraph) and replayed: ~570 kernel launches become
+    one graph launch, so the host no longer paces the GPU.
+
+    What the graph freezes and how it stays correct from replay to replay:
+      * inputs / latents: static device buffers the caller's tensors are copied into before a replay;
+      * the two label scalars (new_betavaegan.py:89-90): a device tensor the BCE kernels read (vg_bce_loss_dev);
+      * Adam's step count: a device counter advanced inside the graph (optim.HipAdam(capturable=True));
+      * Python-side bookkeeping a replay does not execute -- BatchNorm ``num_batches_tracked`` (counted lazily by the
+        modules), Adam's host step counts, the trainer's iteration counter -- is re-applied after each replay from what
+        the capture pass recorded.
+    The capture pass only records (nothing executes); the replay that follows it IS that iteration, so capturing has
+    no side effect on the training state.  Outputs are static tensors, overwritten by the next replay."""
+
+    def __init__(self, trainer, run, inputs, optimizers, bn_modules):
+        self.inputs = {k: torch.empty_like(v) for k, v in inputs.items()}
+        self.labels = torch.zeros(2, dtype=torch.float32, device=trainer.device)     # [real, fake]
+        self.label_values = None
+        self.optimizers, self.bn = optimizers, bn_modules
+        self.graph = torch.cuda.CUDAGraph()
+        for k, v in inputs.items():
+            self.inputs[k].copy_(v)
+        before_nbt = [m._nbt_pending for m in bn_modules]
+        host_steps = [{p: float(o.state[p]["step"]) for g in o.param_groups for p in g["params"] if len(o.state[p])}
+                      for o in optimizers]
+        for o in optimizers:
+            o.prepare_capture()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.out = run(self.inputs, self.labels[0:1], self.labels[1:2])
+        except Exception:
+            # nothing executed: take back what the pass did on the host side
+            for m, n in zip(bn_modules, before_nbt):
+                m._nbt_pending = n
+            for o, hs in zip(optimizers, host_steps):
+                for p, v in hs.items():
+                    o.state[p]["step"].fill_(v)
+                o._captured = []
+            raise
+        self.nbt_delta = [m._nbt_pending - n for m, n in zip(bn_modules, before_nbt)]
+        self.fresh = True          # the capture pass already did the host-side bookkeeping of the first replay
+
+    def replay(self, inputs, real_label, fake_label):
+        for k, v in inputs.items():
+            if v is not self.inputs[k]:
+                self.inputs[k].copy_(v)
+        if (real_label, fake_label) != self.label_values:
+            self.labels[0].fill_(real_label)
+            self.labels[1].fill_(fake_label)
+            self.label_values = (real_label, fake_label)
+        self.graph.replay()
+        if self.fresh:
+            self.fresh = False
+        else:
+            for m, d in zip(self.bn, self.nbt_delta):
+                m._nbt_pending += d
+            for o in self.optimizers:
+                o.replayed()
+        return self.out
+
+
 class BetaVAEGANTrainer:
-    """One replica of the beta-VAE-GAN (new_betavaegan.py:36-53 construction recipe)."""
+    """One replica of the beta-VAE-GAN (new_betavaegan.py:36-53 construction recipe).
+
+    ``graph`` (default: on for a single-process CUDA trainer, VG_GRAPH=0 turns it off): from the third iteration of a
+    batch shape on, `step` replays a HIP graph of the whole iteration (`_CapturedIteration`) instead of launching its
+    ~570 kernels one by one.  Iterations that need the host in the loop stay eager: a ``grad_hook``, data parallelism
+    (the gradient exchange runs from autograd hooks), launch timing (bench.py's instrumented step)."""
 
     def __init__(self, device="cuda", seed=999, beta=25.0, lr=1e-3, opt: Optional[ModelOpt] = None,
-                 data_parallel: Optional[bool] = None, fused_adam: bool = True, capturable: bool = False):
+                 data_parallel: Optional[bool] = None, fused_adam: bool = True, capturable: Optional[bool] = None,
+                 graph: Optional[bool] = None):
         self.opt = opt or ModelOpt()
         self.device = torch.device(device)
         self.beta = float(beta)
+        self.world = _dist_world()
+        self.dp = (self.world > 1) if data_parallel is None else data_parallel
+        on_gpu = self.device.type == "cuda"
+        self.graph = (GRAPH_DEFAULT if graph is None else bool(graph)) and on_gpu and fused_adam and not self.dp
+        if capturable is None:
+            capturable = self.graph
+        self._graphs, self._shape_steps = {}, {}
         torch.manual_seed(seed)                       # new_betavaegan.py:36
         net_eg = VAE(self.opt)                        # :41  (constructed on CPU: same RNG stream
         net_d = Discriminator_celeba(self.opt)        # :43   as the reference => identical weights)
@@ -269,8 +345,6 @@ class BetaVAEGANTrainer:
         fused = fused_adam and self.device.type == "cuda"
         self.optimizerEG = _make_adam(self.netEG.parameters(), lr, fused, capturable)   # :49 (hard-coded 1e-3 there)
         self.optimizerD = _make_adam(self.netD.parameters(), lr, fused, capturable)     # :50
-        self.world = _dist_world()
-        self.dp = (self.world > 1) if data_parallel is None else data_parallel
         self.flat_eg = FlatGrads(self.netEG.parameters()) if self.dp else None
         self.flat_d = FlatGrads(self.netD.parameters()) if self.dp else None
         self.netEG.train()
@@ -304,9 +378,55 @@ class BetaVAEGANTrainer:
     # -- one iteration ------------------------------------------------------------
     def step(self, data, noise=None, eps2=None, eps3=None, real_label=0.9, fake_label=0.1,
              global_batch: Optional[int] = None, grad_hook=None) -> Dict[str, torch.Tensor]:
+        if self.graph and grad_hook is None and ops._timing is None and data.is_cuda \
+                and isinstance(self.optimizerEG, HipAdam) and self.optimizerEG.device_scalars \
+                and not torch.cuda.is_current_stream_capturing():
+            return self._step_graphed(data, noise, eps2, eps3, float(real_label), float(fake_label), global_batch)
         # weights change only at the three optimizer steps below: packed filters are reused between them
         with ops.packed_filter_scope():
             return self._step(data, noise, eps2, eps3, real_label, fake_label, global_batch, grad_hook)
+
+    def _step_graphed(self, data, noise, eps2, eps3, real_label, fake_label, global_batch):
+        B = data.size(0)
+        gb = global_batch if global_batch is not None else B * self.world
+        key = (tuple(data.shape), int(gb), self.beta, self.optimizerEG.param_groups[0]["lr"],
+               self.optimizerD.param_groups[0]["lr"], ops.CONV_ARITH)
+        cap = self._graphs.get(key)
+        if cap is None and self._shape_steps.get(key, 0) < GRAPH_WARM_STEPS:
+            self._shape_steps[key] = self._shape_steps.get(key, 0) + 1
+            with ops.packed_filter_scope():
+                return self._step(data, noise, eps2, eps3, real_label, fake_label, global_batch, None)
+        lat = {}
+        for name, t in (("noise", noise), ("eps2", eps2), ("eps3", eps3)):
+            if t is None:                            # drawn from this replica's stream, in the eager path's order
+                buf = cap.inputs[name] if cap is not None else torch.empty(B, self.opt.n_hidden, device=self.device)
+                t = buf.normal_(generator=self.latent_generator)
+            lat[name] = t
+        inputs = dict(data=data.contiguous(), **lat)
+        if cap is None:
+            if len(self._graphs) >= 4:               # each capture keeps its own memory pool: bound them
+                self._graphs.pop(next(iter(self._graphs)))
+
+            def run(inp, real_dev, fake_dev):
+                with ops.packed_filter_scope():
+                    return self._step(inp["data"], inp["noise"], inp["eps2"], inp["eps3"], real_dev, fake_dev, gb, None)
+            bns = [m for net in (self.netEG, self.netD) for m in net.modules() if hasattr(m, "_nbt_pending")]
+            it0 = self.iteration
+            try:
+                cap = _CapturedIteration(self, run, inputs, [self.optimizerD, self.optimizerEG], bns)
+            except Exception as e:                   # stay correct: this trainer goes on eagerly
+                import warnings
+                warnings.warn(f"HIP-graph capture of the training iteration failed ({type(e).__name__}: {e}); "
+                              "continuing with eager launches")
+                self.iteration = it0
+                self.graph = False
+                with ops.packed_filter_scope():
+                    return self._step(data, noise, eps2, eps3, real_label, fake_label, global_batch, None)
+            self._graphs[key] = cap
+            self.iteration = it0                     # counted below, once per executed iteration
+        out = cap.replay(inputs, real_label, fake_label)
+        self.iteration += 1
+        return out
 
     def _step(self, data, noise, eps2, eps3, real_label, fake_label, global_batch, grad_hook):
         """data (B,3,64,64) in [-1,1]; noise / eps2 / eps3 (B, n_hidden) ~ N(0,1) are drawn on

@@ -281,6 +281,10 @@ size_t vg_sqdiff_workspace_bytes(size_t n);
  * divisor = B locally; the global batch under data parallelism. */
 int vg_bce_loss(const float* p, float target, float* loss, float* gp, int B, float divisor,
                 float gscale, void* stream);
+/* The same with the label read from DEVICE memory (target_dev[0]): the per-iteration soft / flipped label of
+ * new_betavaegan.py:89-90 changes between replays of an iteration captured in a HIP graph. */
+int vg_bce_loss_dev(const float* p, const float* target_dev, float* loss, float* gp, int B, float divisor,
+                    float gscale, void* stream);
 
 /* ---- Adam (experiments/new_betavaegan.py:49-50: optim.Adam defaults, stepped 3x per iteration)
  * For each tensor: m += (1-beta1)(g-m); v = beta2 v + (1-beta2) g^2;
@@ -297,6 +301,16 @@ typedef struct {
 } VgAdamTensor;
 int vg_adam_step(const VgAdamTensor* tensors, int count, double lr, double beta1, double beta2, double eps,
                  double bias_correction1, double bias_correction2_sqrt, void* stream);
+/* The same step with its scalars on the DEVICE, for an iteration captured in a HIP graph (kernel arguments are frozen
+ * at capture; the step count is not).  vg_adam_prepare (one thread) writes scalars[0] = lr / (1 - beta1^step) and
+ * scalars[1] = sqrt(1 - beta2^step), formed in double: with advance_device_counter the device counter step_dev[0] is
+ * advanced by one and used (captured steps); without, the host's `step` (>= 1) is used and -- step_dev may be NULL --
+ * stored in the counter (eager steps between replays keep it current; same expression, same bits).
+ * vg_adam_step_dev is vg_adam_step reading those two scalars. */
+int vg_adam_prepare(double step, double* step_dev, int advance_device_counter, double lr, double beta1, double beta2,
+                    float* scalars, void* stream);
+int vg_adam_step_dev(const VgAdamTensor* tensors, int count, double beta1, double beta2, double eps,
+                     const float* scalars, void* stream);
 
 /* ---- image I/O either side of the step -----------------
  * Input pipeline of dataloader/dataset.py:37-43 (ToTensor + Normalize(mean, std) of a

@@ -284,16 +284,20 @@ def test_load_accepts_prefixless_discriminator_keys(T):
         assert torch.equal(a, b), k
 
 
-def test_hip_adam_matches_torch_adam_and_shares_checkpoints(T):
-    """optim.HipAdam (vg_adam_step) against torch.optim.Adam on the same gradients for 4 steps: parameters
-    and moments agree to a few ulp; state_dict round-trips in both directions."""
-    from disentangle_mlp_amd.optim import HipAdam
+@pytest.mark.parametrize("capturable", [False, True])
+def test_hip_adam_matches_torch_adam_and_shares_checkpoints(T, capturable):
+    """optim.HipAdam (vg_adam_step; capturable: vg_adam_prepare + vg_adam_step_dev, the scalars formed on the device)
+    against torch.optim.Adam on the same gradients for 4 steps: parameters and moments agree to a few ulp; state_dict
+    round-trips in both directions."""
+    from disentangle_mlp_amd import optim as _optim
+    import functools
+    HipAdam = functools.partial(_optim.HipAdam, capturable=capturable)
     g = torch.Generator().manual_seed(21)
     shapes = [(7,), (33, 5), (256, 128, 5, 5), (2048, 1031), (3,), (64, 3, 5, 5)] + [(5, 5)] * 30     # > 24 tensors: 2 launches
     ps_a = [torch.nn.Parameter(torch.randn(*s, generator=g).cuda()) for s in shapes]
     ps_b = [torch.nn.Parameter(p.detach().clone()) for p in ps_a]
     oa, ob = HipAdam(ps_a, lr=1e-3), torch.optim.Adam(ps_b, lr=1e-3)
-    assert isinstance(oa, torch.optim.Adam)
+    assert isinstance(oa, torch.optim.Adam) and isinstance(oa, _optim.HipAdam)
     for it in range(4):
         for pa, pb in zip(ps_a, ps_b):
             gr = torch.randn(*pa.shape, generator=g).cuda() * (10.0 ** (it - 2))
@@ -329,6 +333,52 @@ def test_hip_adam_matches_torch_adam_and_shares_checkpoints(T):
     pe.grad, pf.grad = torch.ones(10).cuda(), torch.ones(10).cuda()
     oe.step(); of.step()
     assert torch.allclose(pe, pf)
+
+
+def test_captured_iteration_equals_eager_bit_for_bit(T):
+    """trainer.BetaVAEGANTrainer(graph=True): from the third iteration of a batch shape on, `step` replays a HIP graph of
+    the whole iteration (inputs and latents through static buffers, labels read from device memory, Adam's step count on
+    the device).  Against the same trainer stepping eagerly: every loss of every iteration, every parameter, BatchNorm
+    buffer (incl. num_batches_tracked, counted on the host) and Adam state afterwards -- identical bits.  Labels change
+    between replays (the 5 % flips of new_betavaegan.py:89-90), latents are drawn by the trainer itself in one iteration,
+    and a second batch shape gets its own capture."""
+    from disentangle_mlp_amd.optim import HipAdam
+    g = torch.Generator().manual_seed(3)
+    batches = [16, 16, 16, 16, 16, 8, 8, 8, 8, 16, 16]
+    labels = [(0.9, 0.1), (0.9, 0.1), (0.9, 0.1), (0.1, 0.1), (0.9, 0.9), (0.9, 0.1), (0.9, 0.1), (0.9, 0.1), (0.1, 0.9),
+              (0.9, 0.1), (0.9, 0.1)]
+    data = [torch.rand(b, 3, 64, 64, generator=g) * 2 - 1 for b in batches]
+    lat = [[torch.randn(b, 128, generator=g) for _ in range(3)] for b in batches]
+    res = {}
+    for mode in ("eager", "graph"):
+        tr = T.BetaVAEGANTrainer(beta=25.0, graph=(mode == "graph"), capturable=True)
+        assert isinstance(tr.optimizerEG, HipAdam) and tr.optimizerEG.device_scalars
+        losses = []
+        for i, b in enumerate(batches):
+            lt = [None, None, None] if i == 4 else [t.cuda() for t in lat[i]]      # iteration 4: the trainer draws them
+            # iteration 9: a hooked iteration stays eager in both trainers -- the replay after it must find Adam's device
+            # step counter current
+            hook = (lambda ph, net: None) if i == 9 else None
+            out = tr.step(data[i].cuda(), *lt, real_label=labels[i][0], fake_label=labels[i][1], grad_hook=hook)
+            losses.append({k: v.clone() for k, v in out.items()})
+        if mode == "graph":
+            assert len(tr._graphs) == 2 and tr.graph                          # both shapes captured, no fallback
+        assert tr.iteration == len(batches)
+        sd = {f"{n}.{k}": v.detach().clone() for n, net in (("eg", tr.netEG), ("d", tr.netD)) for k, v in net.state_dict().items()}
+        for n, o in (("oeg", tr.optimizerEG), ("od", tr.optimizerD)):
+            osd = o.state_dict()
+            for i, st in osd["state"].items():
+                for k, v in st.items():
+                    sd[f"{n}.{i}.{k}"] = v.detach().clone()
+        res[mode] = (losses, sd)
+    for i, (le, lg) in enumerate(zip(res["eager"][0], res["graph"][0])):
+        for k in le:
+            assert torch.equal(le[k], lg[k]), (i, k, float(le[k]), float(lg[k]))
+    assert res["eager"][1].keys() == res["graph"][1].keys()
+    for k, v in res["eager"][1].items():
+        assert torch.equal(v.cpu(), res["graph"][1][k].cpu()), k
+    assert float(res["graph"][1]["oeg.0.step"]) == 2 * len(batches) and float(res["graph"][1]["od.0.step"]) == len(batches)
+    assert int(res["graph"][1]["d.convs.1.num_batches_tracked"]) == 5 * len(batches)
 
 
 # ------------------------------------------------------------------ parity AWAY from the initial weights
