@@ -31,6 +31,7 @@ SIGNATURES = {
     "vg_conv5x5_fwd_packed_stats": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "vg_conv5x5_packed_bf16split_bytes": (_Z, [_I, _I, _I]),
     "vg_conv5x5_pack_bf16split": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "vg_conv5x5_pack_bf16split_multi": (_I, [_P, _I, _I, _P]),
     "vg_convT5x5_fwd_bf16split_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "vg_convT5x5_fwd_bf16split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P]),
     "vg_conv5x5_fwd_bf16split_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
@@ -149,6 +150,12 @@ class ConvFusion(ctypes.Structure):
     """vg_conv_fusion of include/vaegan_hip.h."""
     _fields_ = [("in_scale", c_void_p), ("in_shift", c_void_p), ("in_act", c_int), ("stats", c_void_p),
                 ("stats_floats", c_size_t)]
+
+
+class PackEntry(ctypes.Structure):
+    """VgPackEntry of include/vaegan_hip.h."""
+    _fields_ = [("w", c_void_p), ("packed", c_void_p), ("Cout", c_int), ("Cin", c_int), ("transposed", c_int),
+                ("stride", c_int)]
 
 
 class HipKernelError(RuntimeError):

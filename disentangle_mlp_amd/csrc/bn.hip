@@ -397,6 +397,71 @@ __global__ __launch_bounds__(NT) void bn_finalize_kernel(const T* __restrict__ p
   }
 }
 
+// MANY slots in ONE launch (the ring kernels leave 512-2048 of them at B = 128): a workgroup of 1024 threads owns 8
+// channels, 128 partial-lanes each -- every lane sums every 128th slot (4-16 independent loads), the 128 fp64 sums of a
+// channel are added in a fixed order through LDS (16 lanes x 8, then 16).  Replaces stats_partial + finalize (two launches
+// of ~5 us and a kernel boundary) wherever a channel has <= 4096 slots.
+__global__ __launch_bounds__(1024) void bn_finalize_wide_kernel(const float* __restrict__ stats, int nslots, int C,
+                                                                double count, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta,
+                                                                float* __restrict__ running_mean,
+                                                                float* __restrict__ running_var, float* __restrict__ mean_out,
+                                                                float* __restrict__ invstd_out, float* __restrict__ scale,
+                                                                float* __restrict__ shift, float eps, float momentum) {
+  constexpr int CH = 8, KL = 128;
+  __shared__ double r1[KL][CH], r2[KL][CH];
+  const int cl = threadIdx.x % CH, kl = threadIdx.x / CH;
+  const int c = blockIdx.x * CH + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int k = kl; k < nslots; k += KL) {
+      const float2 v = *reinterpret_cast<const float2*>(stats + ((size_t)k * C + c) * 2);
+      s1 += (double)v.x;
+      s2 += (double)v.y;
+    }
+  r1[kl][cl] = s1;
+  r2[kl][cl] = s2;
+  __syncthreads();
+  if (kl < 16) {                      // 16 lanes per channel: each adds 8 consecutive partial-lanes, in order
+    s1 = 0.0;
+    s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      s1 += r1[kl * 8 + k][cl];
+      s2 += r2[kl * 8 + k][cl];
+    }
+  }
+  __syncthreads();
+  if (kl < 16) {
+    r1[kl][cl] = s1;
+    r2[kl][cl] = s2;
+  }
+  __syncthreads();
+  if (kl == 0 && c < C) {
+    s1 = 0.0;
+    s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      s1 += r1[k][cl];
+      s2 += r2[k][cl];
+    }
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mu = (float)m, is = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * is;
+    mean_out[c] = mu;
+    invstd_out[c] = is;
+    scale[c] = sc;
+    shift[c] = beta[c] - mu * sc;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    if (running_var) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  }
+}
+
 // First stage for MANY slots (a 3 -> 32 first layer at B = 128 leaves 16 384 of them for 32 channels): workgroup
 // (channel block, split) sums its share of the slots into fp64 partials part[c][split][2], in a fixed order.
 __global__ __launch_bounds__(NT) void stats_partial_kernel(const float* __restrict__ stats, int nslots, int C, int nsplit,
@@ -473,6 +538,12 @@ extern "C" int vg_bn_finalize_stats(const float* stats, int nslots, int C, doubl
     hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(cdiv(C, 32)), dim3(NT), 0, st, stats, nslots, 1L, (long)C, C,
                        count, gamma, beta, running_mean, running_var, save_mean, save_invstd, scale, shift, eps,
                        momentum);      // stats[slot][C][2]: channel stride 1, slot stride C
+    VG_CHECK_LAUNCH();
+    return 0;
+  }
+  if (nslots <= 4096) {
+    hipLaunchKernelGGL(bn_finalize_wide_kernel, dim3(cdiv(C, 8)), dim3(1024), 0, st, stats, nslots, C, count, gamma, beta,
+                       running_mean, running_var, save_mean, save_invstd, scale, shift, eps, momentum);
     VG_CHECK_LAUNCH();
     return 0;
   }

@@ -432,12 +432,11 @@ constexpr int PK_CO = 8, PK_PITCH = 401;         // channels per workgroup (512 
 // loads into LDS (400 contiguous floats per channel, or 800 per input channel for the transposed layout) and every
 // (channel, step, k-block) unit is built from there.  (The first version read each value with its own 4-byte load, a
 // lane's 16 values 100 bytes apart and the lanes 12.8 KB apart: 12.7 us for the 6.5 MB filter, 0.29 ms per iteration.)
-__global__ __launch_bounds__(256) void pack_bf16split_kernel(const float* __restrict__ w, bf16x8* __restrict__ p,
-                                                         int Cout, int Cin, int CoutP, int nsteps, int transposed,
-                                                         int S, int planes) {
-  __shared__ float T[PK_CO * PK_PITCH];          // [channel][ci16 * 25 + tap]
+__device__ __forceinline__ void pack_bf16split_body(float* T, const float* __restrict__ w, bf16x8* __restrict__ p,
+                                                    int Cout, int Cin, int CoutP, int nsteps, int transposed, int S,
+                                                    int planes, int bx, int by) {
   const int tid = threadIdx.x;
-  const int co0 = blockIdx.x * PK_CO, c16 = blockIdx.y, nchunks = Cin / 16;
+  const int co0 = bx * PK_CO, c16 = by, nchunks = Cin / 16;
   if (!transposed) {
     for (int e0 = tid; e0 < PK_CO * 400; e0 += 4 * 256) {
       float v[4];
@@ -513,6 +512,34 @@ __global__ __launch_bounds__(256) void pack_bf16split_kernel(const float* __rest
   }
 }
 
+__global__ __launch_bounds__(256) void pack_bf16split_kernel(const float* __restrict__ w, bf16x8* __restrict__ p,
+                                                         int Cout, int Cin, int CoutP, int nsteps, int transposed,
+                                                         int S, int planes) {
+  __shared__ float T[PK_CO * PK_PITCH];          // [channel][ci16 * 25 + tap]
+  pack_bf16split_body(T, w, p, Cout, Cin, CoutP, nsteps, transposed, S, planes, blockIdx.x, blockIdx.y);
+}
+
+// Several filters in ONE launch (every filter an optimizer step has just changed): a pack is latency-bound (8 us for
+// 0.2-6.5 MB), so 6-16 of them side by side take about as long as one.
+constexpr int PK_MAXE = 24;
+struct PackBatch {
+  const float* w[PK_MAXE];
+  bf16x8* p[PK_MAXE];
+  int Cout[PK_MAXE], Cin[PK_MAXE], transposed[PK_MAXE], S[PK_MAXE];
+  unsigned first_block[PK_MAXE + 1];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void pack_bf16split_multi_kernel(PackBatch P, int planes) {
+  __shared__ float T[PK_CO * PK_PITCH];
+  int t = 0;
+  while (t + 1 < P.count && blockIdx.x >= P.first_block[t + 1]) ++t;
+  const int CoutP = (P.Cout[t] + 127) & ~127, nbx = CoutP / PK_CO;
+  const int b = blockIdx.x - P.first_block[t];
+  pack_bf16split_body(T, P.w[t], P.p[t], P.Cout[t], P.Cin[t], CoutP, P.Cin[t] / 16 * 25, P.transposed[t], P.S[t], planes,
+                      b % nbx, b / nbx);
+}
+
 // Forward, deep K on a small grid (the 8 x 8-pixel layers): the 128 x 128 tile with the channel chunks split
 // over k workgroups, partial outputs summed in a fixed order.  1 = no split.
 int fwd_ksplit(int B, int Cin, int H, int W, int Cout, int S) {
@@ -558,6 +585,31 @@ extern "C" int vg_conv5x5_pack_bf16split(const float* w, void* packed, int Cout,
   hipLaunchKernelGGL(pack_bf16split_kernel, dim3(CoutP / PK_CO, Cin / 16), dim3(256), 0,
                      (hipStream_t)stream, w, (bf16x8*)packed, Cout, Cin, CoutP, nsteps, transposed ? 1 : 0, stride, planes);
   VG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vg_conv5x5_pack_bf16split_multi(const VgPackEntry* entries, int count, int planes, void* stream) {
+  if (count < 0 || (count > 0 && !entries) || (planes != 2 && planes != 3)) return VG_ERR_BAD_ARG;
+  int i = 0;
+  while (i < count) {
+    PackBatch P;
+    P.count = 0;
+    unsigned blocks = 0;
+    while (i < count && P.count < PK_MAXE) {
+      const VgPackEntry& E = entries[i++];
+      if (!E.w || !E.packed || E.Cout <= 0 || E.Cin <= 0 || E.Cin % 16 || ((uintptr_t)E.packed & 15) ||
+          (E.stride != 1 && E.stride != 2))
+        return VG_ERR_BAD_ARG;
+      const int k = P.count++;
+      P.w[k] = E.w; P.p[k] = (bf16x8*)E.packed; P.Cout[k] = E.Cout; P.Cin[k] = E.Cin;
+      P.transposed[k] = E.transposed ? 1 : 0; P.S[k] = E.stride;
+      P.first_block[k] = blocks;
+      blocks += (unsigned)(((E.Cout + 127) & ~127) / PK_CO) * (unsigned)(E.Cin / 16);
+    }
+    P.first_block[P.count] = blocks;
+    hipLaunchKernelGGL(pack_bf16split_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, planes);
+    VG_CHECK_LAUNCH();
+  }
   return 0;
 }
 

@@ -13,6 +13,9 @@ from . import ops
 # How the gradient of a convolution bias that feeds a train-mode BatchNorm is
 # produced.  It is analytically zero (BN subtracts the batch mean); the reference
 # accumulates pure rounding noise there.
+# BIAS_GRAD_ZERO: the backward hands autograd NO gradient for that bias (None) -- defined as exactly zero without a
+# fill + accumulate launch per pass; the trainers keep a persistent all-zero ``.grad`` on those parameters
+# (trainer._zero_grads) so that optimizers and gradient exchange see zeros.
 BIAS_GRAD_COMPUTE, BIAS_GRAD_ZERO = 0, 1
 
 
@@ -38,8 +41,7 @@ class Conv5x5Fn(Function):
         if ctx.needs_input_grad[1]:
             gw = ops.conv5x5_wgrad(x, gy, ctx.stride)
         if ctx.needs_input_grad[2]:
-            gb = torch.zeros(w.shape[0], dtype=gy.dtype, device=gy.device) \
-                if ctx.bias_grad == BIAS_GRAD_ZERO else ops.channel_sum(gy)
+            gb = None if ctx.bias_grad == BIAS_GRAD_ZERO else ops.channel_sum(gy)
         return gx, gw, gb, None, None
 
 
@@ -63,8 +65,7 @@ class ConvT5x5Fn(Function):
         if ctx.needs_input_grad[1]:
             gw = ops.conv5x5_wgrad(gy, x, ctx.stride)       # roles swapped
         if ctx.needs_input_grad[2]:
-            gb = torch.zeros(w.shape[1], dtype=gy.dtype, device=gy.device) \
-                if ctx.bias_grad == BIAS_GRAD_ZERO else ops.channel_sum(gy)
+            gb = None if ctx.bias_grad == BIAS_GRAD_ZERO else ops.channel_sum(gy)
         return gx, gw, gb, None, None
 
 
@@ -208,8 +209,7 @@ class ConvStatsFn(Function):
         if ctx.needs_input_grad[1]:
             gw = ops.conv5x5_wgrad(gy, x, s) if tr else ops.conv5x5_wgrad(x, gy, s)
         if ctx.needs_input_grad[2]:
-            gb = torch.zeros(w.shape[1 if tr else 0], dtype=gy.dtype, device=gy.device) \
-                if ctx.bias_grad == BIAS_GRAD_ZERO else ops.channel_sum(gy)
+            gb = None if ctx.bias_grad == BIAS_GRAD_ZERO else ops.channel_sum(gy)
         return gx, gw, gb, None, None, None
 
 
@@ -259,8 +259,7 @@ class BNConvFn(Function):
             gw = ops.conv5x5_wgrad(gy, x, s, in_affine=aff, affine_on_gy=True) if tr \
                 else ops.conv5x5_wgrad(x, gy, s, in_affine=aff)
         if ctx.needs_input_grad[4]:
-            gb = torch.zeros(w.shape[1 if tr else 0], dtype=gy.dtype, device=gy.device) \
-                if ctx.bias_grad == BIAS_GRAD_ZERO else ops.channel_sum(gy)
+            gb = None if ctx.bias_grad == BIAS_GRAD_ZERO else ops.channel_sum(gy)
         return gx, dg, db, gw, gb, None, None, None, None, None, None, None, None, None
 
 

@@ -162,6 +162,13 @@ class HipLinear(nn.Linear):
         return tF.linear(x, self.weight, self.bias)
 
 
+def shadowed_bias_params(net):
+    """The convolution biases whose gradient is defined as exactly zero (they feed a train-mode BatchNorm: HipConv2d /
+    HipConvTranspose2d with ``bn_shadowed``): their backward returns no gradient at all, see functional.BIAS_GRAD_ZERO."""
+    return [m.bias for m in net.modules()
+            if isinstance(m, (HipConv2d, HipConvTranspose2d)) and m.bn_shadowed and m.bias is not None]
+
+
 # --------------------------------------------------------------- building blocks
 # Conv <-> BatchNorm fusion (SURVEY.md K5): inside a chain conv -> BN -> act -> conv -> ... the statistics of every
 # BatchNorm come from the producing convolution's epilogue, and its normalise + activation are applied by the

@@ -183,6 +183,8 @@ def invalidate_packed_filters(params=None):
 def _packed_filter(lib, w, cout, cin, transposed, stride):
     bf16x3 = transposed >= 2                      # 2 / 3: split-bf16 pack of the opt-in modes (conv / transposed conv)
     planes = _planes()
+    if bf16x3 and _pack_log is not None:
+        _pack_log.append((w, cout, cin, transposed, stride))
     n = lib.vg_conv5x5_packed_bf16split_bytes(cout, cin, planes) // 4 if bf16x3 else lib.vg_conv5x5_packed_floats(cout, cin)
     if _pack_scope_depth > 0:
         key = (w.data_ptr(), transposed, stride, tuple(w.shape), planes if bf16x3 else 0)
@@ -207,6 +209,56 @@ def _packed_filter(lib, w, cout, cin, transposed, stride):
     if ent is not None:
         ent[0], ent[1] = True, w._version
     return buf
+
+
+_pack_log = None      # while a list: every split-bf16 pack request appends (weight tensor, cout, cin, kind, stride)
+
+
+class record_pack_requests:
+    """Context: collects which (weight, layout) pairs the convolutions inside it asked for -- a trainer records its
+    first iteration and afterwards re-packs all filters an optimizer step has changed in ONE launch
+    (`prepack_filters`) instead of one launch per filter on first use."""
+
+    def __enter__(self):
+        global _pack_log
+        self._prev, _pack_log = _pack_log, []
+        self.requests = _pack_log
+        return self
+
+    def __exit__(self, *exc):
+        global _pack_log
+        _pack_log = self._prev
+        return False
+
+
+def prepack_filters(requests):
+    """Pack (split-bf16 layout) every listed filter whose cached pack is stale, all in one launch.  ``requests``:
+    (weight, cout, cin, kind, stride) tuples as `record_pack_requests` collects them.  Only inside a
+    `packed_filter_scope` (outside it nothing is cached)."""
+    if _pack_scope_depth <= 0 or not requests:
+        return
+    lib = _lib.load()
+    planes = _planes()
+    if not planes:
+        return
+    todo = []
+    for (w, cout, cin, kind, stride) in requests:
+        key = (w.data_ptr(), kind, stride, tuple(w.shape), planes)
+        ent = _pack_cache.get(key)
+        if ent is not None and ent[0] and ent[1] == w._version:
+            continue
+        if ent is None:
+            n = lib.vg_conv5x5_packed_bf16split_bytes(cout, cin, planes) // 4
+            ent = _pack_cache[key] = [False, -1, torch.empty(n, dtype=torch.float32, device=w.device)]
+        todo.append((w, ent, cout, cin, kind, stride))
+    if not todo:
+        return
+    arr = (_lib.PackEntry * len(todo))()
+    for i, (w, ent, cout, cin, kind, stride) in enumerate(todo):
+        arr[i] = _lib.PackEntry(w.data_ptr(), ent[2].data_ptr(), cout, cin, kind - 2, stride)
+    check(lib.vg_conv5x5_pack_bf16split_multi(arr, len(todo), planes, _stream()), "vg_conv5x5_pack_bf16split_multi")
+    for (w, ent, *_rest) in todo:
+        ent[0], ent[1] = True, w._version
 
 
 def conv_fusable(transposed, cin, cout, stride):

@@ -32,7 +32,7 @@ from torch import optim
 from . import functional as F
 from . import ops
 from .optim import HipAdam
-from .model import VAE, Discriminator_celeba, Generator_celeba, weights_init
+from .model import VAE, Discriminator_celeba, Generator_celeba, weights_init, shadowed_bias_params
 
 
 @dataclass
@@ -62,8 +62,11 @@ class FlatGrads:
 
     exchange_when_alone = False      # tests: run the collectives even in a process group of one
 
-    def __init__(self, params, bucket_bytes=8 << 20, direct_bytes=1 << 20, overlap=True):
+    def __init__(self, params, bucket_bytes=8 << 20, direct_bytes=1 << 20, overlap=True, silent=()):
+        """``silent``: parameters that never receive a gradient from autograd (the biases whose gradient is defined as
+        zero, model.shadowed_bias_params): their zeroed views travel with their bucket, which does not wait for them."""
         self.params = [p for p in params]
+        self._silent = {id(p) for p in silent}
         self.direct = [p.numel() * 4 >= direct_bytes for p in self.params]
         small = [i for i, d in enumerate(self.direct) if not d]
         n = sum(self.params[i].numel() for i in small)
@@ -103,6 +106,8 @@ class FlatGrads:
                 if self.overlap:
                     self._reduce_direct(i)
                 return
+            if id(p) in self._silent:      # (autograd may or may not run AccumulateGrad for a gradient it was not given)
+                return
             b = self.bucket_of[i]
             self._pending[b] -= 1
             if self._pending[b] == 0 and self.overlap:
@@ -132,7 +137,7 @@ class FlatGrads:
         self.flat.zero_()
         for i, p in enumerate(self.params):
             p.grad = None if self.direct[i] else self.views[i]
-        self._pending = [len(b["members"]) for b in self.buckets]
+        self._pending = [sum(1 for i in b["members"] if id(self.params[i]) not in self._silent) for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._direct_done = set()
         self._handles = []
@@ -177,6 +182,21 @@ class FlatGrads:
         """All gradients flattened in parameter order (tests / diagnostics; copies)."""
         return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
                           for p in self.params])
+
+
+def _zero_grads(net):
+    """``net.zero_grad(set_to_none=True)``, except for the convolution biases whose gradient is defined as exactly zero
+    (model.shadowed_bias_params): they keep ONE persistent all-zero ``.grad`` -- their backward returns nothing, so it
+    is never written -- instead of a zero fill and an accumulate launch per pass (35 launches per iteration)."""
+    keep = getattr(net, "_vg_zero_bias_grads", None)
+    if keep is None:
+        keep = net._vg_zero_bias_grads = {id(p) for p in shadowed_bias_params(net)}
+    for p in net.parameters():
+        if id(p) in keep:
+            if p.grad is None or p.grad.shape != p.shape or p.grad.device != p.device:
+                p.grad = torch.zeros_like(p)
+        else:
+            p.grad = None
 
 
 _ONES = {}
@@ -314,7 +334,60 @@ class _CapturedIteration:
         return self.out
 
 
-class BetaVAEGANTrainer:
+class _GraphedSteps:
+    """What the three trainers share to replay their iteration as a HIP graph: `_graph_usable` (may this call be a
+    replay at all) and `_run_graphed` (warm-up count per shape, capture, replay, fallback)."""
+    graph = False
+    iteration = 0
+
+    def _graph_init(self, graph, on_gpu, fused_adam, dp):
+        self.graph = (GRAPH_DEFAULT if graph is None else bool(graph)) and on_gpu and fused_adam and not dp
+        self._graphs, self._shape_steps = {}, {}
+        return self.graph
+
+    def _graph_usable(self, optimizers, data, grad_hook):
+        return (self.graph and grad_hook is None and ops._timing is None and data.is_cuda
+                and all(isinstance(o, HipAdam) and o.device_scalars for o in optimizers)
+                and not torch.cuda.is_current_stream_capturing())
+
+    def _draw_into(self, cap, name, batch):
+        """A latent the caller left to the trainer: drawn from this replica's stream straight into the capture's static
+        buffer (same generator, same order as the eager path's torch.randn)."""
+        buf = cap.inputs[name] if cap is not None else torch.empty(batch, self.opt.n_hidden, device=self.device)
+        return buf.normal_(generator=self.latent_generator)
+
+    def _run_graphed(self, key, make_inputs, labels, run, optimizers, nets, eager):
+        """``key``: everything the capture freezes (shapes, divisors, learning rates, arithmetic).  ``make_inputs(cap)``
+        -> dict of device tensors; ``run(inputs, real_dev, fake_dev)`` -> the iteration on static tensors; ``eager()``:
+        the same iteration launched kernel by kernel (the first GRAPH_WARM_STEPS iterations of a shape, and for good
+        after a failed capture)."""
+        cap = self._graphs.get(key)
+        if cap is None and self._shape_steps.get(key, 0) < GRAPH_WARM_STEPS:
+            self._shape_steps[key] = self._shape_steps.get(key, 0) + 1
+            return eager()
+        inputs = make_inputs(cap)
+        if cap is None:
+            if len(self._graphs) >= 4:               # each capture keeps its own memory pool: bound them
+                self._graphs.pop(next(iter(self._graphs)))
+            bns = [m for net in nets for m in net.modules() if hasattr(m, "_nbt_pending")]
+            it0 = self.iteration
+            try:
+                cap = _CapturedIteration(self, run, inputs, optimizers, bns)
+            except Exception as e:                   # stay correct: this trainer goes on eagerly
+                import warnings
+                warnings.warn(f"HIP-graph capture of the training iteration failed ({type(e).__name__}: {e}); "
+                              "continuing with eager launches")
+                self.iteration = it0
+                self.graph = False
+                return eager()
+            self._graphs[key] = cap
+            self.iteration = it0                     # counted below, once per executed iteration
+        out = cap.replay(inputs, *labels)
+        self.iteration += 1
+        return out
+
+
+class BetaVAEGANTrainer(_GraphedSteps):
     """One replica of the beta-VAE-GAN (new_betavaegan.py:36-53 construction recipe).
 
     ``graph`` (default: on for a single-process CUDA trainer, VG_GRAPH=0 turns it off): from the third iteration of a
@@ -330,11 +403,9 @@ class BetaVAEGANTrainer:
         self.beta = float(beta)
         self.world = _dist_world()
         self.dp = (self.world > 1) if data_parallel is None else data_parallel
-        on_gpu = self.device.type == "cuda"
-        self.graph = (GRAPH_DEFAULT if graph is None else bool(graph)) and on_gpu and fused_adam and not self.dp
+        self._graph_init(graph, self.device.type == "cuda", fused_adam, self.dp)
         if capturable is None:
             capturable = self.graph
-        self._graphs, self._shape_steps = {}, {}
         torch.manual_seed(seed)                       # new_betavaegan.py:36
         net_eg = VAE(self.opt)                        # :41  (constructed on CPU: same RNG stream
         net_d = Discriminator_celeba(self.opt)        # :43   as the reference => identical weights)
@@ -345,14 +416,15 @@ class BetaVAEGANTrainer:
         fused = fused_adam and self.device.type == "cuda"
         self.optimizerEG = _make_adam(self.netEG.parameters(), lr, fused, capturable)   # :49 (hard-coded 1e-3 there)
         self.optimizerD = _make_adam(self.netD.parameters(), lr, fused, capturable)     # :50
-        self.flat_eg = FlatGrads(self.netEG.parameters()) if self.dp else None
-        self.flat_d = FlatGrads(self.netD.parameters()) if self.dp else None
+        self.flat_eg = FlatGrads(self.netEG.parameters(), silent=shadowed_bias_params(self.netEG)) if self.dp else None
+        self.flat_d = FlatGrads(self.netD.parameters(), silent=shadowed_bias_params(self.netD)) if self.dp else None
         self.netEG.train()
         self.netD.train()
         self.iteration = 0
         self._eg_params = [p for p in self.netEG.parameters() if p.dim() == 4]   # convolution filters
         self._d_params = [p for p in self.netD.parameters() if p.dim() == 4]
         self.rank = _dist_rank()
+        self._pack_plan = None
         self.latent_generator = _latent_generator(self.device, seed, self.rank)
         self.label_rng = _shared_label_rng(seed)          # used by train_epoch when world > 1: one draw per GLOBAL batch
 
@@ -365,7 +437,7 @@ class BetaVAEGANTrainer:
         if flat is not None:
             flat.zero_and_attach()
         else:
-            net.zero_grad(set_to_none=True)
+            _zero_grads(net)
 
     def _exchange(self, flat):
         if flat is not None and (self.world > 1 or FlatGrads.exchange_when_alone):
@@ -378,9 +450,7 @@ class BetaVAEGANTrainer:
     # -- one iteration ------------------------------------------------------------
     def step(self, data, noise=None, eps2=None, eps3=None, real_label=0.9, fake_label=0.1,
              global_batch: Optional[int] = None, grad_hook=None) -> Dict[str, torch.Tensor]:
-        if self.graph and grad_hook is None and ops._timing is None and data.is_cuda \
-                and isinstance(self.optimizerEG, HipAdam) and self.optimizerEG.device_scalars \
-                and not torch.cuda.is_current_stream_capturing():
+        if self._graph_usable((self.optimizerD, self.optimizerEG), data, grad_hook):
             return self._step_graphed(data, noise, eps2, eps3, float(real_label), float(fake_label), global_batch)
         # weights change only at the three optimizer steps below: packed filters are reused between them
         with ops.packed_filter_scope():
@@ -391,42 +461,21 @@ class BetaVAEGANTrainer:
         gb = global_batch if global_batch is not None else B * self.world
         key = (tuple(data.shape), int(gb), self.beta, self.optimizerEG.param_groups[0]["lr"],
                self.optimizerD.param_groups[0]["lr"], ops.CONV_ARITH)
-        cap = self._graphs.get(key)
-        if cap is None and self._shape_steps.get(key, 0) < GRAPH_WARM_STEPS:
-            self._shape_steps[key] = self._shape_steps.get(key, 0) + 1
+
+        def make_inputs(cap):                        # latents left to the trainer: drawn in the eager path's order
+            lat = {name: (t if t is not None else self._draw_into(cap, name, B))
+                   for name, t in (("noise", noise), ("eps2", eps2), ("eps3", eps3))}
+            return dict(data=data.contiguous(), **lat)
+
+        def run(inp, real_dev, fake_dev):
+            with ops.packed_filter_scope():
+                return self._step(inp["data"], inp["noise"], inp["eps2"], inp["eps3"], real_dev, fake_dev, gb, None)
+
+        def eager():
             with ops.packed_filter_scope():
                 return self._step(data, noise, eps2, eps3, real_label, fake_label, global_batch, None)
-        lat = {}
-        for name, t in (("noise", noise), ("eps2", eps2), ("eps3", eps3)):
-            if t is None:                            # drawn from this replica's stream, in the eager path's order
-                buf = cap.inputs[name] if cap is not None else torch.empty(B, self.opt.n_hidden, device=self.device)
-                t = buf.normal_(generator=self.latent_generator)
-            lat[name] = t
-        inputs = dict(data=data.contiguous(), **lat)
-        if cap is None:
-            if len(self._graphs) >= 4:               # each capture keeps its own memory pool: bound them
-                self._graphs.pop(next(iter(self._graphs)))
-
-            def run(inp, real_dev, fake_dev):
-                with ops.packed_filter_scope():
-                    return self._step(inp["data"], inp["noise"], inp["eps2"], inp["eps3"], real_dev, fake_dev, gb, None)
-            bns = [m for net in (self.netEG, self.netD) for m in net.modules() if hasattr(m, "_nbt_pending")]
-            it0 = self.iteration
-            try:
-                cap = _CapturedIteration(self, run, inputs, [self.optimizerD, self.optimizerEG], bns)
-            except Exception as e:                   # stay correct: this trainer goes on eagerly
-                import warnings
-                warnings.warn(f"HIP-graph capture of the training iteration failed ({type(e).__name__}: {e}); "
-                              "continuing with eager launches")
-                self.iteration = it0
-                self.graph = False
-                with ops.packed_filter_scope():
-                    return self._step(data, noise, eps2, eps3, real_label, fake_label, global_batch, None)
-            self._graphs[key] = cap
-            self.iteration = it0                     # counted below, once per executed iteration
-        out = cap.replay(inputs, real_label, fake_label)
-        self.iteration += 1
-        return out
+        return self._run_graphed(key, make_inputs, (real_label, fake_label), run, [self.optimizerD, self.optimizerEG],
+                                 (self.netEG, self.netD), eager)
 
     def _step(self, data, noise, eps2, eps3, real_label, fake_label, global_batch, grad_hook):
         """data (B,3,64,64) in [-1,1]; noise / eps2 / eps3 (B, n_hidden) ~ N(0,1) are drawn on
@@ -441,6 +490,27 @@ class BetaVAEGANTrainer:
             eps2 = self.draw_latents(B)
         if eps3 is None:
             eps3 = self.draw_latents(B)
+        # Packed filters: the first iteration records which (weight, layout) pairs its convolutions ask for; from then
+        # on all filters a network's optimizer step has changed are re-packed in ONE launch (32 launches -> 3)
+        plan = self._pack_plan
+        if plan is None:
+            with ops.record_pack_requests() as rec:
+                out = self._step_body(data, noise, eps2, eps3, real_label, fake_label, global_batch, grad_hook, None)
+            d_ptrs = {p.data_ptr() for p in netD.parameters()}
+            seen, self._pack_plan = set(), {"d": [], "eg": []}
+            for r in rec.requests:
+                k = (r[0].data_ptr(), r[3], r[4])
+                if k not in seen:
+                    seen.add(k)
+                    self._pack_plan["d" if r[0].data_ptr() in d_ptrs else "eg"].append(r)
+            return out
+        return self._step_body(data, noise, eps2, eps3, real_label, fake_label, global_batch, grad_hook, plan)
+
+    def _step_body(self, data, noise, eps2, eps3, real_label, fake_label, global_batch, grad_hook, plan):
+        netEG, netD = self.netEG, self.netD
+        B = data.size(0)
+        if plan is not None:
+            ops.prepack_filters(plan["d"] + plan["eg"])
         # BCE is a mean over the GLOBAL batch (DataParallel gathers the outputs before the loss); equal
         # shards are assumed unless the caller says otherwise (train_epoch passes the loader's count)
         gb = global_batch if global_batch is not None else B * self.world
@@ -460,6 +530,8 @@ class BetaVAEGANTrainer:
             grad_hook("D", netD)
         self.optimizerD.step()
         ops.invalidate_packed_filters(self._d_params)
+        if plan is not None:
+            ops.prepack_filters(plan["d"])
         out["errD_real"], out["errD_fake"] = err_real.detach(), err_fake.detach()
         out["D_x_sum"] = p_real.detach().sum()
 
@@ -482,6 +554,8 @@ class BetaVAEGANTrainer:
             grad_hook("EG2", netEG)
         self.optimizerEG.step()
         ops.invalidate_packed_filters(self._eg_params)
+        if plan is not None:
+            ops.prepack_filters(plan["eg"])
         out.update(errG_fake=err_g_fake.detach(), errG_recon=err_g_rec.detach(), sim=sim.detach(),
                    mse_dec=mse2.detach())
 
@@ -534,6 +608,74 @@ class BetaVAEGANTrainer:
         n = len(loader.dataset)
         return mse_sum / n, mse_sum / n, dx_sum / n, dx_sum / n
 
+    # -- the experiment script's ``__main__`` (new_betavaegan.py:211-267) -----------------
+    def fit(self, loader, epochs, start_epoch=0, model_path=None, label_rng=None, calc_fid=False, n_samples=1000,
+            fid_path_recons=None, fid_path_pretrained=None, get_fid=None, log=None, max_iterations=None, verbose=True):
+        """The training half of the reference's ``__main__`` (new_betavaegan.py:218-246): per epoch ``train(epoch)``
+        (`train_epoch`), the checkpoint ``{model_path}/model_{epoch+1}.tar`` (:222-228), optionally
+        ``generate_fid_samples`` + ``get_fid`` (:231-235), the printed line (:237-238) and the logger row (:241-246:
+        ``log(row)``, e.g. the reference's ``Logger.log``).  ``get_fid`` defaults to this package's
+        (`fid.get_fid`; it needs Inception weights on disk, so ``calc_fid`` is off unless asked for).  Under data
+        parallelism every rank trains, rank 0 writes.  Returns the rows (with ``Dx`` added)."""
+        import os
+        from . import image_io
+        rows = []
+        for epoch in range(start_epoch, epochs):
+            enc_loss, dec_loss, dis_loss, dx = self.train_epoch(loader, label_rng=label_rng, max_iterations=max_iterations)
+            fid = "N/A"
+            if self.rank == 0:
+                with torch.no_grad():
+                    if model_path is not None:
+                        self.save(os.path.join(model_path, f"model_{epoch + 1}.tar"), epoch + 1)
+                    if calc_fid:
+                        if get_fid is None:
+                            from .fid import get_fid
+                        image_io.generate_fid_samples(self.netEG.decode, epoch, n_samples, self.opt.n_hidden,
+                                                      fid_path_recons, device=self.device)
+                        fid = get_fid(fid_path_recons, fid_path_pretrained)
+                if verbose:
+                    print("====> Epoch: {} Avg Encoder Loss: {:.4f} Avg Decoder Loss: {:.4f} Avg Discriminator Loss: {:.4f} "
+                          "FID: {} Dx: {:.4f}".format(epoch, enc_loss, dec_loss, dis_loss, fid, dx), flush=True)
+                row = {"Epoch": epoch, "Avg Eec Loss": enc_loss, "Avg Dnc Loss": dec_loss, "Avg Dis Loss": dis_loss,
+                       "FID": fid}
+                if log is not None:
+                    log(row)
+                rows.append(dict(row, Dx=dx))
+        return rows
+
+    def evaluate(self, load_paths, test_loader=None, start_epoch=0, calc_fid=False, n_samples=1000, fid_path_samples=None,
+                 fid_path_pretrained=None, get_fid=None, test_recons=False, test_results_path_recons=None,
+                 test_results_path_originals="", test_samples=False, test_results_path_samples=None):
+        """The evaluation half (new_betavaegan.py:248-267): for every checkpoint of ``load_paths`` -- load it, renumber
+        its epoch the way the reference does so that files of several checkpoints do not overwrite each other (:252-254),
+        then FID samples + score (:256-259), one grid of test reconstructions with ``nrow=1`` (+ the originals, :260-263)
+        and five samples named after ``start_epoch`` (:264-267: the reference passes ``start_epoch`` there, so several
+        checkpoints write the same file; kept).  Train-mode BatchNorm throughout: the reference never calls ``.eval()``
+        (SURVEY.md section 3.1 item 5).  Returns one dict per checkpoint."""
+        from . import image_io
+        out, tmp_epoch = [], 0
+        for m in load_paths:
+            epoch = self.load(m)
+            epoch = epoch if epoch != tmp_epoch and tmp_epoch < epoch else tmp_epoch + 1
+            tmp_epoch = epoch
+            res = {"path": m, "epoch": epoch, "FID": "N/A"}
+            with torch.no_grad():
+                if calc_fid:
+                    if get_fid is None:
+                        from .fid import get_fid
+                    image_io.generate_fid_samples(self.netEG.decode, epoch, n_samples, self.opt.n_hidden, fid_path_samples,
+                                                  device=self.device)
+                    res["FID"] = get_fid(fid_path_samples, fid_path_pretrained)
+                if test_recons:
+                    image_io.gen_reconstructions(lambda x: self.netEG(x.to(self.device))[0], test_loader, epoch,
+                                                 test_results_path_recons, nrow=1,
+                                                 path_for_originals=test_results_path_originals, device=self.device)
+                if test_samples:
+                    image_io.generate_samples(self.netEG.decode, start_epoch, 5, self.opt.n_hidden,
+                                              test_results_path_samples, nrow=1, device=self.device)
+            out.append(res)
+        return out
+
     # -- checkpoint (new_betavaegan.py:203-209, 222-228) --------------------------------
     def checkpoint(self, epoch):
         """The reference's dict.  ``discriminator_model`` keys carry the ``module.`` prefix
@@ -563,11 +705,11 @@ class BetaVAEGANTrainer:
         return ck["epoch"]
 
 
-class VAETrainer:
-    """new_vae.py:33-37 construction, :39-48 loss, :53-59 step."""
+class VAETrainer(_GraphedSteps):
+    """new_vae.py:33-37 construction, :39-48 loss, :53-59 step.  ``graph``: as BetaVAEGANTrainer."""
 
     def __init__(self, device="cuda", seed=999, beta=1.0, lr=3e-3, opt: Optional[ModelOpt] = None,
-                 fused_adam: bool = True, capturable: bool = False):
+                 fused_adam: bool = True, capturable: Optional[bool] = None, graph: Optional[bool] = None):
         self.opt = opt or ModelOpt()
         self.device = torch.device(device)
         self.beta = float(beta)
@@ -575,15 +717,28 @@ class VAETrainer:
         m = VAE(self.opt)
         m.apply(weights_init)
         self.model = m.to(self.device)
-        self.optimizer = _make_adam(self.model.parameters(), lr, fused_adam and self.device.type == "cuda", capturable)
         self.world = _dist_world()
-        self.flat = FlatGrads(self.model.parameters()) if self.world > 1 else None
+        self._graph_init(graph, self.device.type == "cuda", fused_adam, self.world > 1)
+        self.optimizer = _make_adam(self.model.parameters(), lr, fused_adam and self.device.type == "cuda",
+                                    self.graph if capturable is None else capturable)
+        self.flat = FlatGrads(self.model.parameters(), silent=shadowed_bias_params(self.model)) if self.world > 1 else None
         self.latent_generator = _latent_generator(self.device, seed, _dist_rank())
         self.model.train()
 
     def step(self, data, eps=None):
-        with ops.packed_filter_scope():       # one optimizer step at the end: packs live for the iteration
-            return self._step(data, eps)
+        def eager():
+            with ops.packed_filter_scope():       # one optimizer step at the end: packs live for the iteration
+                return self._step(data, eps)
+        if not self._graph_usable((self.optimizer,), data, None):
+            return eager()
+
+        def run(inp, real_dev, fake_dev):
+            with ops.packed_filter_scope():
+                return self._step(inp["data"], inp["eps"])
+        key = (tuple(data.shape), self.beta, self.optimizer.param_groups[0]["lr"], ops.CONV_ARITH)
+        return self._run_graphed(key, lambda cap: dict(data=data.contiguous(),
+                                                       eps=eps if eps is not None else self._draw_into(cap, "eps", data.size(0))),
+                                 (0.0, 0.0), run, [self.optimizer], (self.model,), eager)
 
     def _step(self, data, eps):
         if eps is None:                       # model.py:534, from this replica's own stream
@@ -591,7 +746,7 @@ class VAETrainer:
         if self.flat is not None:
             self.flat.zero_and_attach()
         else:
-            self.optimizer.zero_grad(set_to_none=True)
+            _zero_grads(self.model)
         recon, mu, logvar, kld = self.model.forward_with_kl(data, eps, self.beta)
         mse = F.reconstruction_loss(recon, data)
         _backward([mse, kld])
@@ -619,13 +774,14 @@ class VAETrainer:
         return {"epoch": epoch, "VAE_model": self.model.state_dict(), "optimizer": self.optimizer.state_dict()}
 
 
-class GANTrainer:
+class GANTrainer(_GraphedSteps):
     """new_gan.py:47-61 construction, :66-141 step.  Data parallel like the beta-VAE-GAN driver (the
     reference wraps both nets in nn.DataParallel, new_gan.py:51-53): replica-local BatchNorm, one
-    gradient exchange (SUM) per optimizer step, BCE divided by the global batch."""
+    gradient exchange (SUM) per optimizer step, BCE divided by the global batch.  ``graph``: as
+    BetaVAEGANTrainer."""
 
     def __init__(self, device="cuda", seed=999, lr=3e-3, opt: Optional[ModelOpt] = None, fused_adam: bool = True,
-                 data_parallel: Optional[bool] = None):
+                 data_parallel: Optional[bool] = None, graph: Optional[bool] = None):
         self.opt = opt or ModelOpt()
         self.device = torch.device(device)
         torch.manual_seed(seed)
@@ -635,12 +791,13 @@ class GANTrainer:
         d.apply(weights_init)
         self.netG, self.netD = g.to(self.device), d.to(self.device)
         fused = fused_adam and self.device.type == "cuda"
-        self.optimizerG = _make_adam(self.netG.parameters(), lr, fused)
-        self.optimizerD = _make_adam(self.netD.parameters(), lr, fused)
         self.world = _dist_world()
         self.dp = (self.world > 1) if data_parallel is None else data_parallel
-        self.flat_g = FlatGrads(self.netG.parameters()) if self.dp else None
-        self.flat_d = FlatGrads(self.netD.parameters()) if self.dp else None
+        self._graph_init(graph, self.device.type == "cuda", fused_adam, self.dp)
+        self.optimizerG = _make_adam(self.netG.parameters(), lr, fused, self.graph)
+        self.optimizerD = _make_adam(self.netD.parameters(), lr, fused, self.graph)
+        self.flat_g = FlatGrads(self.netG.parameters(), silent=shadowed_bias_params(self.netG)) if self.dp else None
+        self.flat_d = FlatGrads(self.netD.parameters(), silent=shadowed_bias_params(self.netD)) if self.dp else None
         self.latent_generator = _latent_generator(self.device, seed, _dist_rank())
         self.label_rng = _shared_label_rng(seed)
         self.netG.train()
@@ -650,7 +807,7 @@ class GANTrainer:
         if flat is not None:
             flat.zero_and_attach()
         else:
-            net.zero_grad(set_to_none=True)
+            _zero_grads(net)
 
     def _exchange(self, flat):
         if flat is not None and (self.world > 1 or FlatGrads.exchange_when_alone):
@@ -658,8 +815,23 @@ class GANTrainer:
 
     def step(self, data, noise=None, real_label=0.9, fake_label=0.1, global_batch: Optional[int] = None,
              grad_hook=None):
-        with ops.packed_filter_scope():
-            return self._step(data, noise, real_label, fake_label, global_batch, grad_hook)
+        def eager():
+            with ops.packed_filter_scope():
+                return self._step(data, noise, real_label, fake_label, global_batch, grad_hook)
+        if not self._graph_usable((self.optimizerD, self.optimizerG), data, grad_hook):
+            return eager()
+        B = data.size(0)
+        gb = global_batch if global_batch is not None else B * self.world
+
+        def run(inp, real_dev, fake_dev):
+            with ops.packed_filter_scope():
+                return self._step(inp["data"], inp["noise"], real_dev, fake_dev, gb, None)
+        key = (tuple(data.shape), int(gb), self.optimizerG.param_groups[0]["lr"], self.optimizerD.param_groups[0]["lr"],
+               ops.CONV_ARITH)
+        return self._run_graphed(key, lambda cap: dict(data=data.contiguous(),
+                                                       noise=noise if noise is not None else self._draw_into(cap, "noise", B)),
+                                 (float(real_label), float(fake_label)), run, [self.optimizerD, self.optimizerG],
+                                 (self.netG, self.netD), eager)
 
     def _step(self, data, noise, real_label, fake_label, global_batch, grad_hook):
         B = data.size(0)

@@ -126,6 +126,14 @@ size_t vg_convT5x5_fwd_bf16split_stats_floats(int B, int Cin, int H, int W, int 
 size_t vg_conv5x5_packed_bf16split_bytes(int Cout, int Cin, int planes);
 int vg_conv5x5_pack_bf16split(const float* w, void* packed, int Cout, int Cin, int transposed, int stride,
                            int planes, void* stream);
+/* The same for several filters in one launch (`entries` is a HOST array; 24 filters per kernel launch): what a
+ * training iteration calls after each optimizer step for every filter that step has changed. */
+typedef struct {
+  const float* w;
+  void* packed;
+  int Cout, Cin, transposed, stride;
+} VgPackEntry;
+int vg_conv5x5_pack_bf16split_multi(const VgPackEntry* entries, int count, int planes, void* stream);
 size_t vg_conv5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride);
 int vg_conv5x5_fwd_bf16split(const float* x, const void* packed, const float* bias, float* y,
                           int B, int Cin, int H, int W, int Cout, int stride, int planes,

@@ -224,3 +224,39 @@ def test_loader_publishes_the_global_batch_of_a_ragged_tail():
         got = [(c.tolist(), ld.last_global_batch) for c in ld.index_batches(order)]
         assert [gb for _, gb in got] == [16, 16, 5]          # the BCE mean of the tail runs over 5 images
         assert len(got[2][0]) == (3 if rank == 0 else 2)     # DataParallel's scatter: ceil(5/2), rest
+
+
+# ------------------------------------------------------------------ __main__ of the experiment script (:211-267)
+def test_fit_and_evaluate_follow_the_reference_main(tmp_path, monkeypatch, capsys):
+    """fit: per epoch train_epoch -> model_{epoch+1}.tar -> FID -> the printed line -> the logger row; evaluate: per
+    checkpoint the reference's epoch renumbering, FID samples, nrow=1 reconstructions, five samples named after
+    start_epoch.  Kernels stubbed (CPU): the control flow, file names and arguments are what is checked."""
+    from disentangle_mlp_amd import image_io
+    from disentangle_mlp_amd.trainer import BetaVAEGANTrainer
+    tr = BetaVAEGANTrainer(device="cpu")
+    calls = []
+    tr.train_epoch = lambda loader, label_rng=None, max_iterations=None: (calls.append(("train", loader)) or (3.0, 3.0, 0.5, 0.5))
+    monkeypatch.setattr(image_io, "generate_fid_samples", lambda fn, epoch, n, nh, path, device="cuda": calls.append(("fid_samples", epoch, n, nh, path)))
+    monkeypatch.setattr(image_io, "gen_reconstructions", lambda fn, dl, epoch, path, nrow=8, path_for_originals="", device="cuda": calls.append(("recons", epoch, path, nrow, path_for_originals)))
+    monkeypatch.setattr(image_io, "generate_samples", lambda fn, epoch, n, nh, path, nrow=8, device="cuda": calls.append(("samples", epoch, n, path, nrow)))
+    logged = []
+    rows = tr.fit("LOADER", epochs=3, start_epoch=1, model_path=str(tmp_path), calc_fid=True, n_samples=7,
+                  fid_path_recons="FIDDIR", fid_path_pretrained="PRE", get_fid=lambda a, b: 12.5 if (a, b) == ("FIDDIR", "PRE") else None,
+                  log=logged.append)
+    assert [r["Epoch"] for r in rows] == [1, 2] and logged == [{k: v for k, v in r.items() if k != "Dx"} for r in rows]
+    assert logged[0] == {"Epoch": 1, "Avg Eec Loss": 3.0, "Avg Dnc Loss": 3.0, "Avg Dis Loss": 0.5, "FID": 12.5}
+    assert sorted(os.listdir(tmp_path)) == ["model_2.tar", "model_3.tar"]          # {model_path}/model_{epoch+1}.tar
+    ck = torch.load(tmp_path / "model_3.tar", weights_only=False)
+    assert ck["epoch"] == 3 and all(k.startswith("module.") for k in ck["discriminator_model"])
+    assert calls == [("train", "LOADER"), ("fid_samples", 1, 7, 128, "FIDDIR"), ("train", "LOADER"), ("fid_samples", 2, 7, 128, "FIDDIR")]
+    assert "====> Epoch: 2 Avg Encoder Loss: 3.0000 Avg Decoder Loss: 3.0000 Avg Discriminator Loss: 0.5000 FID: 12.5 Dx: 0.5000" in capsys.readouterr().out
+    # evaluate: checkpoints of epochs 2, 3 and 3 again -> 2, 3, 4 (the reference's "quick fix" renumbering)
+    calls.clear()
+    paths = [str(tmp_path / "model_2.tar"), str(tmp_path / "model_3.tar"), str(tmp_path / "model_3.tar")]
+    res = tr.evaluate(paths, test_loader="TEST", start_epoch=0, calc_fid=True, n_samples=4, fid_path_samples="S", fid_path_pretrained="PRE",
+                      get_fid=lambda a, b: 1.0, test_recons=True, test_results_path_recons="R", test_results_path_originals="O",
+                      test_samples=True, test_results_path_samples="T")
+    assert [r["epoch"] for r in res] == [2, 3, 4] and all(r["FID"] == 1.0 for r in res)
+    assert calls[:3] == [("fid_samples", 2, 4, 128, "S"), ("recons", 2, "R", 1, "O"), ("samples", 0, 5, "T", 1)]
+    assert [c for c in calls if c[0] == "recons"] == [("recons", e, "R", 1, "O") for e in (2, 3, 4)]
+

@@ -381,6 +381,36 @@ def test_captured_iteration_equals_eager_bit_for_bit(T):
     assert int(res["graph"][1]["d.convs.1.num_batches_tracked"]) == 5 * len(batches)
 
 
+def test_vae_and_gan_captured_steps_equal_eager(T):
+    """VAETrainer (new_vae.py) and GANTrainer (new_gan.py) replay their iteration as a HIP graph the same way: losses
+    of five iterations and the final weights bit for bit against eager stepping."""
+    g = torch.Generator().manual_seed(4)
+    data = [torch.rand(8, 3, 64, 64, generator=g) * 2 - 1 for _ in range(5)]
+    lat = [torch.randn(8, 128, generator=g) for _ in range(5)]
+    labels = [(0.9, 0.1), (0.9, 0.1), (0.9, 0.1), (0.1, 0.1), (0.9, 0.9)]
+    for make, call, nets in (
+            (lambda gr: T.VAETrainer(beta=1.0, graph=gr, capturable=True), lambda tr, i: tr.step(data[i].cuda(), lat[i].cuda()),
+             lambda tr: (tr.model,)),
+            (lambda gr: T.GANTrainer(graph=gr), lambda tr, i: tr.step(data[i].cuda(), lat[i].cuda(), real_label=labels[i][0],
+                                                                      fake_label=labels[i][1]), lambda tr: (tr.netG, tr.netD))):
+        res = {}
+        for mode in (False, True):
+            tr = make(mode)
+            if not mode and hasattr(tr, "optimizerG"):       # eager twin of the GAN: the same device-scalar Adam arithmetic
+                from disentangle_mlp_amd.optim import HipAdam
+                tr.optimizerG = HipAdam(tr.netG.parameters(), lr=3e-3, capturable=True)
+                tr.optimizerD = HipAdam(tr.netD.parameters(), lr=3e-3, capturable=True)
+            losses = [{k: v.clone() for k, v in call(tr, i).items()} for i in range(5)]
+            if mode:
+                assert len(tr._graphs) == 1 and tr.graph
+            res[mode] = (losses, {f"{j}.{k}": v.detach().clone() for j, n in enumerate(nets(tr)) for k, v in n.state_dict().items()})
+        for i in range(5):
+            for k, v in res[False][0][i].items():
+                assert torch.equal(v, res[True][0][i][k]), (i, k)
+        for k, v in res[False][1].items():
+            assert torch.equal(v, res[True][1][k]), k
+
+
 # ------------------------------------------------------------------ parity AWAY from the initial weights
 def _trained_oracle(k_iters, batch, seed=31, lr=3e-4):
     """The oracle trained for k iterations on the host (fp32, the reference's schedule).  lr 3e-4 rather than the
