@@ -50,9 +50,6 @@ SIGNATURES = {
     "vg_conv5x5_wgrad_bf16split": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _I, _I, _P]),
     "vg_conv5x5_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "vg_conv5x5_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
-    "vg_gemm_nt_bf16split_workspace_bytes": (_Z, [_I, _I, _I]),
-    "vg_gemm_nt_bf16split": (_I, [_P, _P, _P, _P, _I, _I, _I, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long, _I,
-                                  _P, _Z, _P]),
     "vg_channel_sum": (_I, [_P, _P, _I, _I, _I, _P, _Z, _P]),
     "vg_bn_workspace_bytes": (_Z, [_I]),
     "vg_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P, _Z, _P]),

@@ -108,10 +108,9 @@ DEFER_WGRAD = __import__("os").environ.get("VG_DEFER_WGRAD", "1") != "0"      # 
 
 
 class LinearFn(Function):
-    """nn.Linear (model.py:460-471, 402-408, 490-492).  With ops.LINEAR_SPLIT on the split-bf16 GEMM (ops.linear_*: the
-    convolutions' fp32-equivalent arithmetic; a GEMM whose reduction length is not a multiple of 32 -- the weight
-    gradient at batches that are not -- goes to the vendor library), otherwise on the vendor fp32 GEMM.  Inside
-    `deferred_wgrad()` the weight gradient of a layer with >= 2^20 weights is batched over its passes."""
+    """nn.Linear (model.py:460-471, 402-408, 490-492) on the vendor fp32 GEMMs (algorithm table:
+    tuned_gemms.py).  Exists for `deferred_wgrad()`: inside it the weight gradient of a layer with >= 2^20 weights is
+    batched over its passes.  (Round 2's split-bf16 GEMM for these layers was removed: DESIGN.md section 4.5.)"""
 
     @staticmethod
     def forward(ctx, x, w, bias):
@@ -120,8 +119,6 @@ class LinearFn(Function):
         ctx.defer = dctx if (dctx is not None and ctx.needs_input_grad[1] and w.numel() >= DEFER_MIN_WEIGHTS) else None
         if ctx.defer is not None:
             dctx.pending[id(w)] = dctx.pending.get(id(w), 0) + 1
-        if ops.linear_split_ok(x.shape[1], w.numel()):
-            return ops.linear_fwd(x, w, bias)
         return torch.nn.functional.linear(x, w, bias)
 
     @staticmethod
@@ -131,7 +128,7 @@ class LinearFn(Function):
         gy = gy.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = ops.linear_dgrad(gy, w) if ops.linear_split_ok(gy.shape[1], w.numel()) else gy @ w
+            gx = gy @ w
         if ctx.needs_input_grad[2]:
             gb = gy.sum(0)
         if ctx.needs_input_grad[1]:
@@ -147,7 +144,7 @@ class LinearFn(Function):
                     if len(pairs) > 1:
                         wg, wx = torch.cat([p[0] for p in pairs]), torch.cat([p[1] for p in pairs])
             if wg is not None:
-                gw = ops.linear_wgrad(wg, wx) if ops.linear_split_ok(wg.shape[0], w.numel()) else wg.t() @ wx
+                gw = wg.t() @ wx
         return gx, gw, gb
 
 

@@ -147,16 +147,13 @@ class HipSigmoid(nn.Module):
 
 
 class HipLinear(nn.Linear):
-    """Linear layer on the vendor fp32 GEMM (hipBLASLt through torch).  With ops.LINEAR_SPLIT
-    (VG_LINEAR_SPLIT=1) the layers with >= 2^20 weights (16384 <-> 2048, 128 -> 16384) run this package's split-bf16
-    GEMM instead (csrc/gemm_split.hip: forward, data and weight gradient) -- measured level with the vendor kernel,
-    hence opt-in.  Refuses CPU tensors like every other layer here."""
+    """Linear layer on the vendor fp32 GEMM (hipBLASLt / rocBLAS through torch; trainers load the measured
+    algorithm table of tuned_gemms.py).  Refuses CPU tensors like every other layer here."""
 
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("disentangle_mlp_amd modules need CUDA/ROCm tensors (no CPU fallback)")
-        # big layers go through this package's Function: the split GEMM when it is switched on, and the batched weight
-        # gradient of functional.deferred_wgrad() (the same vendor GEMMs otherwise)
+        # big layers go through this package's Function: the batched weight gradient of functional.deferred_wgrad()
         if self.weight.numel() >= F.DEFER_MIN_WEIGHTS and x.dim() == 2:
             return F.linear(x, self.weight, self.bias)
         return tF.linear(x, self.weight, self.bias)

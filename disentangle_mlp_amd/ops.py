@@ -455,62 +455,6 @@ def conv5x5_wgrad(x, gy, stride, out=None, in_affine=None, affine_on_gy=False):
     return dw
 
 
-# ------------------------------------------------------------------- Linear layers
-# The Linear GEMMs of the big layers (16384 <-> 2048, 128 -> 16384) on this package's split-bf16 GEMM
-# (csrc/gemm_split.hip) instead of the vendor fp32 GEMM.  Opt-in (VG_LINEAR_SPLIT=1 or ops.LINEAR_SPLIT = True): at
-# B = 128 the kernel measures level with the vendor library on the 16384 x 2048 layers (85-115 us against 88-107 us:
-# the weight is used once, so splitting it into planes costs as many VALU cycles as its 6 MFMA products), and only
-# wins on the decoder's 128 -> 16384 data gradient (34 us against 69 us) -- DESIGN.md section 4.
-LINEAR_SPLIT = os.environ.get("VG_LINEAR_SPLIT", "0") == "1"
-
-
-def _gemm_nt(A, B, bias, C, M, N, K, ars, aks, brs, bks):
-    lib = _lib.load()
-    need = lib.vg_gemm_nt_bf16split_workspace_bytes(M, N, K)
-    ws = workspace(need, A.device) if need else None
-    check(lib.vg_gemm_nt_bf16split(A.data_ptr(), B.data_ptr(), _ptr(bias), C.data_ptr(), M, N, K, ars, aks, brs, bks,
-                                   _planes(), _ptr(ws), ws.numel() if need else 0, _stream()), "vg_gemm_nt_bf16split")
-    return C
-
-
-LINEAR_SPLIT_MAX_WEIGHTS = int(os.environ.get("VG_LINEAR_SPLIT_MAX", "0"))     # > 0: only layers with at most this many weights
-
-
-def linear_split_ok(reduction, nweights=0):
-    """The split-bf16 GEMM takes a Linear GEMM when it is switched on, the active arithmetic is a split one, the
-    reduction length is a multiple of 32 and the layer is not above LINEAR_SPLIT_MAX_WEIGHTS (when that is set)."""
-    if LINEAR_SPLIT_MAX_WEIGHTS > 0 and nweights > LINEAR_SPLIT_MAX_WEIGHTS:
-        return False
-    return LINEAR_SPLIT and bool(_planes()) and reduction % 32 == 0
-
-
-def linear_fwd(x, w, bias):
-    """y = x W^T + bias (nn.Linear forward, model.py:460-471): x (M, K), w (N, K)."""
-    _req(x, "x"), _req(w, "w")
-    M, K = x.shape
-    N = w.shape[0]
-    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    return _gemm_nt(x, w, bias, y, M, N, K, K, 1, K, 1)
-
-
-def linear_dgrad(gy, w):
-    """gx = gy W: gy (M, N), w (N, K) -> (M, K); the reduction runs over N, W is read with its row index contiguous."""
-    _req(gy, "gy"), _req(w, "w")
-    M, N = gy.shape
-    K = w.shape[1]
-    gx = torch.empty((M, K), dtype=torch.float32, device=gy.device)
-    return _gemm_nt(gy, w, None, gx, M, K, N, N, 1, 1, K)
-
-
-def linear_wgrad(gy, x):
-    """gW = gy^T x: gy (M, N), x (M, K) -> (N, K); the reduction runs over the batch M (both operands strided)."""
-    _req(gy, "gy"), _req(x, "x")
-    M, N = gy.shape
-    K = x.shape[1]
-    gw = torch.empty((N, K), dtype=torch.float32, device=gy.device)
-    return _gemm_nt(gy, x, None, gw, N, K, M, 1, N, 1, K)
-
-
 def channel_sum(g):
     lib = _lib.load()
     _req(g, "g")

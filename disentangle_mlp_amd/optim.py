@@ -38,6 +38,7 @@ class HipAdam(optim.Adam):
         self._dev = {}            # group index -> (device step counter float64[1], scalars float32[2])
         self._captured = []       # per captured step() call: the parameters it stepped (host bookkeeping of a replay)
         self._debt = 0            # replays whose host-side step counts have not been added yet (flushed lazily)
+        self.state_generation = 0 # bumped by load_state_dict: captured graphs point at the moment tensors of one generation
         self.register_state_dict_pre_hook(lambda opt: opt._flush_replays())
 
     def _native_ok(self, group):
@@ -89,7 +90,10 @@ class HipAdam(optim.Adam):
         self._debt += times
 
     def load_state_dict(self, state_dict):
+        """(torch replaces the moment tensors: a graph captured before holds the old ones -- `state_generation` tells the
+        trainers to capture anew.)"""
         self._debt, self._captured = 0, []
+        self.state_generation += 1
         return super().load_state_dict(state_dict)
 
     @torch.no_grad()

@@ -334,6 +334,13 @@ class _CapturedIteration:
         return self.out
 
 
+def _use_tuned_gemms(device):
+    """The Linear layers' vendor GEMMs with the measured algorithm table (tuned_gemms.py), on the GPU."""
+    if torch.device(device).type == "cuda":
+        from . import tuned_gemms
+        tuned_gemms.enable()
+
+
 class _GraphedSteps:
     """What the three trainers share to replay their iteration as a HIP graph: `_graph_usable` (may this call be a
     replay at all) and `_run_graphed` (warm-up count per shape, capture, replay, fallback)."""
@@ -400,6 +407,7 @@ class BetaVAEGANTrainer(_GraphedSteps):
                  graph: Optional[bool] = None):
         self.opt = opt or ModelOpt()
         self.device = torch.device(device)
+        _use_tuned_gemms(self.device)
         self.beta = float(beta)
         self.world = _dist_world()
         self.dp = (self.world > 1) if data_parallel is None else data_parallel
@@ -460,7 +468,8 @@ class BetaVAEGANTrainer(_GraphedSteps):
         B = data.size(0)
         gb = global_batch if global_batch is not None else B * self.world
         key = (tuple(data.shape), int(gb), self.beta, self.optimizerEG.param_groups[0]["lr"],
-               self.optimizerD.param_groups[0]["lr"], ops.CONV_ARITH)
+               self.optimizerD.param_groups[0]["lr"], ops.CONV_ARITH, self.optimizerEG.state_generation,
+               self.optimizerD.state_generation)
 
         def make_inputs(cap):                        # latents left to the trainer: drawn in the eager path's order
             lat = {name: (t if t is not None else self._draw_into(cap, name, B))
@@ -712,6 +721,7 @@ class VAETrainer(_GraphedSteps):
                  fused_adam: bool = True, capturable: Optional[bool] = None, graph: Optional[bool] = None):
         self.opt = opt or ModelOpt()
         self.device = torch.device(device)
+        _use_tuned_gemms(self.device)
         self.beta = float(beta)
         torch.manual_seed(seed)
         m = VAE(self.opt)
@@ -735,7 +745,8 @@ class VAETrainer(_GraphedSteps):
         def run(inp, real_dev, fake_dev):
             with ops.packed_filter_scope():
                 return self._step(inp["data"], inp["eps"])
-        key = (tuple(data.shape), self.beta, self.optimizer.param_groups[0]["lr"], ops.CONV_ARITH)
+        key = (tuple(data.shape), self.beta, self.optimizer.param_groups[0]["lr"], ops.CONV_ARITH,
+               self.optimizer.state_generation)
         return self._run_graphed(key, lambda cap: dict(data=data.contiguous(),
                                                        eps=eps if eps is not None else self._draw_into(cap, "eps", data.size(0))),
                                  (0.0, 0.0), run, [self.optimizer], (self.model,), eager)
@@ -784,6 +795,7 @@ class GANTrainer(_GraphedSteps):
                  data_parallel: Optional[bool] = None, graph: Optional[bool] = None):
         self.opt = opt or ModelOpt()
         self.device = torch.device(device)
+        _use_tuned_gemms(self.device)
         torch.manual_seed(seed)
         g = Generator_celeba(self.opt)
         d = Discriminator_celeba(self.opt)
@@ -827,7 +839,7 @@ class GANTrainer(_GraphedSteps):
             with ops.packed_filter_scope():
                 return self._step(inp["data"], inp["noise"], real_dev, fake_dev, gb, None)
         key = (tuple(data.shape), int(gb), self.optimizerG.param_groups[0]["lr"], self.optimizerD.param_groups[0]["lr"],
-               ops.CONV_ARITH)
+               ops.CONV_ARITH, self.optimizerG.state_generation, self.optimizerD.state_generation)
         return self._run_graphed(key, lambda cap: dict(data=data.contiguous(),
                                                        noise=noise if noise is not None else self._draw_into(cap, "noise", B)),
                                  (float(real_label), float(fake_label)), run, [self.optimizerD, self.optimizerG],

@@ -3,7 +3,6 @@
 # wrong by construction):  abl_build.sh <ring|wx> <bits> ...   ->  experiments/abl/libabl_<which>_<bits>.so
 #   ring: conv_ring.hip,       -DVG_RING_ABL=<bits>
 #   wx:   wgrad_bf16split.hip, -DVG_WX_ABL=<bits>
-#   gemm: gemm_split.hip,      -DVG_GEMM_ABL=<bits>
 #   tfwd: conv_thin_fwd.hip,   -DVG_TF_ABL=<bits>
 #   twg:  conv_thin_wgrad.hip, -DVG_TWG_ABL=<bits>
 set -e
@@ -13,10 +12,9 @@ which=$1; shift
 case $which in
   ring) SRC=conv_ring; DEF=VG_RING_ABL ;;
   wx)   SRC=wgrad_bf16split; DEF=VG_WX_ABL ;;
-  gemm) SRC=gemm_split; DEF=VG_GEMM_ABL ;;
   tfwd) SRC=conv_thin_fwd; DEF=VG_TF_ABL ;;
   twg)  SRC=conv_thin_wgrad; DEF=VG_TWG_ABL ;;
-  *) echo "usage: $0 <ring|wx|gemm|tfwd|twg> <bits> ..."; exit 2 ;;
+  *) echo "usage: $0 <ring|wx|tfwd|twg> <bits> ..."; exit 2 ;;
 esac
 mkdir -p experiments/abl
 OBJS=$(ls $C/build/*.o | grep -v "/$SRC.o")

@@ -235,19 +235,6 @@ int vg_affine_act(const float* x, const float* scale, const float* shift, float*
                   void* stream);
 
 
-/* ---- Linear layers in the split-bf16 arithmetic ------------------------------------------------------------
- * C[m][n] = sum_k A(m,k) * B(n,k) (+ bias[n]), A(m,k) = A[m*a_row_stride + k*a_k_stride], B alike; C row-major
- * [M][N].  Per operand either the reduction index is contiguous (k stride 1; row stride % 4 == 0, 16-byte aligned
- * base) or the row index is (row stride 1).  K % 32 == 0.  One entry point serves nn.Linear (model.py:460-471,
- * 402-408, 490-492) forward y = x W^T (A = x, B = W), data gradient gx = gy W (A = gy, B = W with b_row_stride = 1,
- * b_k_stride = in_features) and weight gradient gW = gy^T x (A = gy with a_row_stride = 1, B = x with b_row_stride
- * = 1; K = batch).  planes as for the convolutions (3 = fp32-equivalent).  Small reductions are split over
- * workgroups: query the workspace (partial tiles, summed in a fixed order). */
-size_t vg_gemm_nt_bf16split_workspace_bytes(int M, int N, int K);
-int vg_gemm_nt_bf16split(const float* A, const float* B, const float* bias, float* C, int M, int N, int K,
-                         long a_row_stride, long a_k_stride, long b_row_stride, long b_k_stride, int planes,
-                         void* workspace, size_t workspace_bytes, void* stream);
-
 /* ---- elementwise activations ------------------------------------------------
  * LeakyReLU(0.2) after lth_features (model.py:404), tanh after deconv4
  * (model.py:509,565), both with an optional per-channel bias add fused in:

@@ -182,7 +182,6 @@ def test_deferred_linear_weight_gradient_is_the_sum_over_passes(monkeypatch):
     the concatenated passes (by whichever backward node runs last), the same gradients as autograd's two GEMMs + add;
     a forward without its backward inside the context is an error."""
     from disentangle_mlp_amd import functional as HF, ops
-    monkeypatch.setattr(ops, "LINEAR_SPLIT", False)
     monkeypatch.setattr(HF, "DEFER_MIN_WEIGHTS", 1)
     monkeypatch.setattr(HF, "DEFER_WGRAD", True)
     torch.manual_seed(0)
@@ -231,4 +230,22 @@ def test_fused_chain_falls_back_to_module_calls_when_hooked():
     h = d.convs[1].register_forward_pre_hook(lambda m, i: None)
     assert M._has_hooks(mods)
     h.remove()
+
+
+def test_tuned_gemm_table_is_well_formed_and_inert_without_a_gpu():
+    """tuned_gemms: the shipped vendor-GEMM algorithm table parses (validators first, then one row per GEMM shape with a
+    solution name and a positive time), covers the three 16384 <-> 2048 GEMMs of the benchmark batch, and enable() is a
+    no-op on a box without a GPU (and when VG_TUNED_GEMMS=0)."""
+    from disentangle_mlp_amd import tuned_gemms
+    rows = [l.strip().split(",") for l in open(tuned_gemms.TABLE) if l.strip()]
+    vals = [r for r in rows if r[0] == "Validator"]
+    ops = [r for r in rows if r[0] != "Validator"]
+    assert {v[1] for v in vals} >= {"PT_VERSION", "GCN_ARCH_NAME", "HIPBLASLT_VERSION", "ROCBLAS_VERSION"}
+    assert any(v[1] == "GCN_ARCH_NAME" and v[2].startswith("gfx950") for v in vals)
+    assert ops and all(len(r) == 4 and r[0].startswith("Gemm") and float(r[3]) > 0 for r in ops)
+    keys = {r[1] for r in ops}
+    assert {"tn_2048_128_16384_ld_16384_16384_2048", "nn_16384_128_2048_ld_16384_2048_16384",
+            "nt_16384_2048_128_ld_16384_2048_16384"} <= keys          # forward, data gradient, weight gradient at M = 128
+    if not torch.cuda.is_available():
+        assert tuned_gemms.enable() is False
 

@@ -874,22 +874,3 @@ def test_thin_kernels_bf16x3(H):
         assert_close(H.conv5x5_wgrad(x3.cuda(), x32.cuda(), 1), gw_ref, 2e-5, "thin wgrad, 2 planes")
     finally:
         H.CONV_ARITH = prev
-
-
-# ------------------------------------------------------------------ Linear layers on the split-bf16 GEMM
-@pytest.mark.parametrize("M,N,K", [(128, 2048, 16384), (128, 16384, 128), (4, 2048, 16384), (96, 200, 160), (32, 130, 64)])
-def test_linear_split_gemms(H, M, N, K, monkeypatch):
-    """vg_gemm_nt_bf16split as nn.Linear's three GEMMs (forward with bias, data gradient, weight gradient -- the
-    latter only when the batch is a multiple of 32) against the fp64 oracle: 3e-6 relative L2, the convolutions'
-    tolerance (reductions up to 16384 terms: fp32 accumulation error grows like sqrt(K) * 6e-8)."""
-    g = torch.Generator().manual_seed(80)
-    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
-    gy = torch.randn(M, N, generator=g)
-    tol = 3e-6 if os.environ.get("VG_CONV_ARITH", "bf16x6") != "bf16x3" else 2e-5
-    monkeypatch.setattr(H, "LINEAR_SPLIT", True)          # opt-in path (ops.LINEAR_SPLIT)
-    assert H.linear_split_ok(K)
-    assert_close(H.linear_fwd(x.cuda(), w.cuda(), b.cuda()), x.double() @ w.double().t() + b.double(), tol, "linear fwd")
-    if N % 32 == 0:
-        assert_close(H.linear_dgrad(gy.cuda(), w.cuda()), gy.double() @ w.double(), tol, "linear dgrad")
-    if M % 32 == 0:
-        assert_close(H.linear_wgrad(gy.cuda(), x.cuda()), gy.double().t() @ x.double(), tol, "linear wgrad")

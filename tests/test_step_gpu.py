@@ -3,6 +3,7 @@ vectors generated from the imported reference and (b) the oracle run live on the
 host CPU with the same seeded inputs.  fp32 path; tolerances are stated per check
 (reference fp32-vs-fp64 gap is ~1e-6 relative)."""
 import math
+import os
 
 import pytest
 import torch
@@ -364,6 +365,18 @@ def test_captured_iteration_equals_eager_bit_for_bit(T):
         if mode == "graph":
             assert len(tr._graphs) == 2 and tr.graph                          # both shapes captured, no fallback
         assert tr.iteration == len(batches)
+        # a checkpoint loaded in between: torch replaces Adam's moment tensors, so the captures made before must not be
+        # replayed (HipAdam.state_generation): one more iteration, back to the checkpoint, four iterations from there
+        import copy
+        ckpt = copy.deepcopy(tr.checkpoint(1))
+        x16, l16 = data[0].cuda(), [t.cuda() for t in lat[0]]
+        after = {k: v.clone() for k, v in tr.step(x16, *l16).items()}
+        tr.load(ckpt)
+        again = [{k: v.clone() for k, v in tr.step(x16, *l16).items()} for _ in range(4)]
+        assert all(torch.equal(after[k], again[0][k]) for k in after)         # the same iteration from the same state
+        if mode == "graph":
+            assert len(tr._graphs) == 3                                       # captured anew after the load
+        losses += again
         sd = {f"{n}.{k}": v.detach().clone() for n, net in (("eg", tr.netEG), ("d", tr.netD)) for k, v in net.state_dict().items()}
         for n, o in (("oeg", tr.optimizerEG), ("od", tr.optimizerD)):
             osd = o.state_dict()
@@ -377,8 +390,21 @@ def test_captured_iteration_equals_eager_bit_for_bit(T):
     assert res["eager"][1].keys() == res["graph"][1].keys()
     for k, v in res["eager"][1].items():
         assert torch.equal(v.cpu(), res["graph"][1][k].cpu()), k
-    assert float(res["graph"][1]["oeg.0.step"]) == 2 * len(batches) and float(res["graph"][1]["od.0.step"]) == len(batches)
-    assert int(res["graph"][1]["d.convs.1.num_batches_tracked"]) == 5 * len(batches)
+    n_steps = len(batches) + 4                      # + the four iterations after the reload (the one before it was undone)
+    assert float(res["graph"][1]["oeg.0.step"]) == 2 * n_steps and float(res["graph"][1]["od.0.step"]) == n_steps
+    assert int(res["graph"][1]["d.convs.1.num_batches_tracked"]) == 5 * n_steps
+
+
+def test_tuned_gemm_table_is_accepted_on_this_installation(T):
+    """The shipped vendor-GEMM algorithm table (tuned_gemms.py) was measured on this image: its validators match, so a
+    trainer switches TunableOp on in look-up mode (no tuning at run time)."""
+    import torch.cuda.tunable as tunable
+    from disentangle_mlp_amd import tuned_gemms
+    T.BetaVAEGANTrainer(beta=25.0)
+    if os.environ.get("VG_TUNED_GEMMS", "1") != "0" and not os.environ.get("PYTORCH_TUNABLEOP_ENABLED"):
+        assert tuned_gemms.enable() is True
+        assert tunable.is_enabled() and not tunable.tuning_is_enabled()
+        assert len(tunable.get_results()) >= 20
 
 
 def test_vae_and_gan_captured_steps_equal_eager(T):
@@ -489,34 +515,29 @@ def test_gradients_at_trained_weights_vs_oracle(T):
     assert all(w[0] <= 1.0 for w in worst.values()), worst
 
 
-def test_short_trajectory_tracks_the_oracle(T):
-    """scripts/trajectory_vs_oracle.py as a test: both engines run 6 iterations on the same inputs (B = 16).
-    After Adam's first sign-like step the two are chaotic twins (one LeakyReLU unit of D's 16 x 2048 Dis_l features
-    on the other side of zero moves every gradient behind it by 0.8 / sqrt(32768) = 4.4e-3 -- measured between the
-    reference's own fp32 and fp64 runs, scripts/diag_kl_signs.py -- and the next sign-like step turns that into tens of
-    thousands of weights stepping the other way), so the bounds are on trends: D(x) within 0.02 absolute,
-    reconstruction error within 8 % at every iteration; the first iteration's phase-1 numbers at 2e-5 and its KL at 3 %
-    (conftest.LOSS_TOL).  The beta-weighted KL of iterations 1 and 2 -- 25 x a sum of exp(logvar) right after
-    sign-like updates of every encoder weight -- is bounded by the reference itself: the test evaluates the
-    reference's trajectory three ways (fp32 on 16 threads, fp32 on 1 thread, fp64: they disagree by up to 2.6x there)
-    and requires the build's KL inside [min / 1.5, 1.5 max] of those three; later iterations: finite and positive."""
-    n_it, batch = 6, 16
-    g = torch.Generator().manual_seed(7)
+def _smooth_batches(n_it, batch, seed=7):
+    g = torch.Generator().manual_seed(seed)
     base = torch.randn(4 * batch, 3, 8, 8, generator=g)
     data = torch.tanh(torch.nn.functional.interpolate(base, size=64, mode="bilinear"))
     rnd = [[torch.randn(batch, 128, generator=g) for _ in range(3)] for _ in range(n_it)]
+    return data, rnd
 
-    def oracle_kls(n, threads, dtype):
-        """beta*KL of the reference's first n iterations, evaluated with `threads` threads in `dtype`."""
-        torch.set_num_threads(threads)
-        eg, d, oeg, od = osteps.build_nets(dtype=dtype)
-        try:
-            return [osteps.betavaegan_step(eg, d, oeg, od, data[(it % 4) * batch:(it % 4 + 1) * batch].to(dtype),
-                                           *[t.to(dtype) for t in rnd[it]], beta=25.0)["kld"] for it in range(n)]
-        finally:
-            torch.set_num_threads(16)
-    kl_refs = [oracle_kls(3, 1, torch.float32), oracle_kls(3, 16, torch.float64)]
+
+def test_short_trajectory_tracks_the_oracle(T):
+    """scripts/trajectory_vs_oracle.py as a test: both engines run 6 iterations FREELY on the same inputs (B = 16).
+    After Adam's first sign-like step the two are chaotic twins (one LeakyReLU unit of D's 16 x 2048 Dis_l features
+    on the other side of zero moves every gradient behind it by 0.8 / sqrt(32768) = 4.4e-3 -- measured between the
+    reference's own fp32 and fp64 runs, scripts/diag_kl_signs.py -- and the next sign-like step turns that into tens of
+    thousands of weights stepping the other way), so the bounds of a free run are on trends: D(x) within 0.02 absolute,
+    reconstruction error within 8 % at every iteration; the first iteration's phase-1 numbers at 2e-5 and its KL at 3 %
+    (conftest.LOSS_TOL).  The beta-weighted KL of LATER iterations of a FREE run cannot be bounded usefully: this
+    build's iteration-1 value moved from 190 k to 692 k when nothing but the vendor library's algorithm for the Linear
+    GEMMs changed (the reference's own three evaluations: 276 k / 361 k / 315 k) -- it is only required to stay finite
+    here, and is bounded where it can be, one iteration ahead of a common state, by
+    `test_one_iteration_ahead_of_the_oracle_state`."""
+    n_it, batch = 6, 16
     torch.set_num_threads(16)
+    data, rnd = _smooth_batches(n_it, batch)
     tr = T.BetaVAEGANTrainer(beta=25.0)
     eg, d, oeg, od = osteps.build_nets()
     for it in range(n_it):
@@ -530,13 +551,47 @@ def test_short_trajectory_tracks_the_oracle(T):
         assert close(float(out["mse_enc"]), ref["mse_enc"], 0.08), (it, float(out["mse_enc"]), ref["mse_enc"])
         assert close(float(out["mse_dec"]), ref["mse_dec"], 0.08), (it, float(out["mse_dec"]), ref["mse_dec"])
         kl = float(out["kld"])
-        if it == 0:
-            assert abs(kl / ref["kld"] - 1) <= 0.03, (it, kl, ref["kld"])
-        elif it <= 2:
-            three = [ref["kld"], kl_refs[0][it], kl_refs[1][it]]
-            assert min(three) / 1.5 <= kl <= 1.5 * max(three), (it, kl, three)
-        else:
-            assert math.isfinite(kl) and kl > 0, (it, kl)
+        assert (abs(kl / ref["kld"] - 1) <= 0.03) if it == 0 else (math.isfinite(kl) and kl > 0), (it, kl, ref["kld"])
+
+
+def test_one_iteration_ahead_of_the_oracle_state(T):
+    """What CAN be bounded after the first Adam step: along the oracle's own trajectory (fp32, lr 1e-3, B = 16) the
+    oracle's complete state -- weights, BatchNorm buffers, both Adam states: the reference's checkpoint dict -- is
+    loaded into the HIP trainer before EVERY iteration, and into the oracle in fp64; all run the same iteration from
+    the same state.  Every loss of that iteration, the beta-weighted KL and the encoder-phase reconstruction error
+    after two more Adam steps included, must agree with the oracle's within max(the stated tolerance of
+    conftest.LOSS_TOL, 1.5 x the reference's own fp64-vs-fp32 deviation from that state).  Measured
+    (scripts/diag_resync.py): KL +0.9 % / -3.3 % / 0.0 % at iterations 0 / 1 / 2 where the reference's fp64 run
+    deviates +0.1 % / -13 % / +31 %."""
+    import copy
+    n_it, batch = 4, 16
+    torch.set_num_threads(16)
+    data, rnd = _smooth_batches(n_it, batch)
+    eg, d, oeg, od = osteps.build_nets()
+    tr = T.BetaVAEGANTrainer(beta=25.0, seed=3)            # different init: everything comes from the loaded state
+    worst = {}
+    for it in range(n_it):
+        x = data[(it % 4) * batch:(it % 4 + 1) * batch]
+        state = copy.deepcopy({"epoch": it, "encoder_decoder_model": eg.state_dict(),
+                               "discriminator_model": {"module." + k: v for k, v in d.state_dict().items()},
+                               "encoder_decoder_optimizer": oeg.state_dict(), "discriminator_optimizer": od.state_dict()})
+        eg64, d64, oeg64, od64 = osteps.build_nets(dtype=torch.float64)
+        eg64.load_state_dict(state["encoder_decoder_model"])
+        d64.load_state_dict({k[len("module."):]: v for k, v in state["discriminator_model"].items()})
+        oeg64.load_state_dict(copy.deepcopy(state["encoder_decoder_optimizer"]))
+        od64.load_state_dict(copy.deepcopy(state["discriminator_optimizer"]))
+        r64 = osteps.betavaegan_step(eg64, d64, oeg64, od64, x.double(), *[t.double() for t in rnd[it]], beta=25.0)
+        tr.load(copy.deepcopy(state))
+        out = tr.step(x.cuda(), *[t.cuda() for t in rnd[it]])
+        ref = osteps.betavaegan_step(eg, d, oeg, od, x, *rnd[it], beta=25.0)        # advances the trajectory
+        assert abs(float(out["D_x_sum"]) / batch - ref["D_x"]) <= 2e-5 + 1.5 * abs(r64["D_x"] - ref["D_x"]), (it, "D_x")
+        for k in ("errD_real", "errD_fake", "errG_fake", "errG_recon", "sim", "mse_dec", "kld", "mse_enc"):
+            own = gap(r64[k], ref[k])                       # the reference against itself, from the same state
+            tol = max(LOSS_TOL[k], 1.5 * own)
+            dev = gap(float(out[k]), ref[k])
+            worst[k] = max(worst.get(k, 0.0), dev)
+            assert dev <= tol, (it, k, float(out[k]), ref[k], r64[k], tol)
+    assert worst["kld"] <= 0.2 and worst["mse_enc"] <= 0.05, worst      # whatever the reference's own spread was
 
 
 def test_train_epoch_on_device_loader_vs_oracle_loop(T):
