@@ -162,6 +162,90 @@ __global__ __launch_bounds__(NT) void bce_kernel(const float* __restrict__ p, fl
   if (threadIdx.x == 0 && loss) loss[0] = (float)(t * inv_div);
 }
 
+// K11 of SURVEY.md section 2.1: the discriminator's head -- Linear(2048 -> 1) + Sigmoid (model.py:406-408) -- and
+// nn.BCELoss against the iteration's label (new_betavaegan.py:53,101,118,153-154) in ONE launch each way, instead of a
+// GEMV, a sigmoid, a BCE kernel (forward) and a scale, a sigmoid', a bias sum and two GEMMs (backward).
+// Forward: one workgroup of 16 wavefronts; a wavefront owns a row at a time (32 elements per lane as 16-byte loads, one
+// 64-lane shuffle sum), the row terms of the loss are added in a fixed order in double.  Same expressions, in the same
+// fp32 operations, as bias_act (sigmoid), bce_kernel and act_bwd: p, the loss, and dlogit = dBCE/dp * p (1 - p).
+__global__ __launch_bounds__(1024) void dot_sigmoid_bce_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ w,
+                                                                   const float* __restrict__ bias, float target,
+                                                                   const float* __restrict__ target_dev,
+                                                                   float* __restrict__ p_out, float* __restrict__ loss,
+                                                                   float* __restrict__ dlogit, int B, int K, float inv_div) {
+  __shared__ double red[16];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (target_dev) target = target_dev[0];
+  const float b0 = bias ? bias[0] : 0.f;
+  double wave_total = 0.0;
+  for (int b = wid; b < B; b += 16) {
+    const float* row = feat + (size_t)b * K;
+    float s = 0.f;
+    if ((K & 3) == 0) {
+      for (int j = 4 * lane; j < K; j += 256) {
+        const float4 x = *reinterpret_cast<const float4*>(row + j);
+        const float4 v = *reinterpret_cast<const float4*>(w + j);
+        s = fmaf(x.x, v.x, s);
+        s = fmaf(x.y, v.y, s);
+        s = fmaf(x.z, v.z, s);
+        s = fmaf(x.w, v.w, s);
+      }
+    } else {
+      for (int j = lane; j < K; j += 64) s = fmaf(row[j], w[j], s);
+    }
+    s = wave_allsum(s);
+    const float v = 1.f / (1.f + expf(-(s + b0)));
+    const float lp = fmaxf(logf(v), -100.f), l1p = fmaxf(logf(1.f - v), -100.f);
+    wave_total += -(double)(target * lp + (1.f - target) * l1p);
+    if (lane == 0) {
+      p_out[b] = v;
+      if (dlogit) dlogit[b] = (inv_div * (v - target) / fmaxf(v * (1.f - v), 1e-12f)) * v * (1.f - v);
+    }
+  }
+  if (lane == 0) red[wid] = wave_total;
+  __syncthreads();
+  if (threadIdx.x == 0 && loss) {
+    double t = 0.0;
+    for (int i = 0; i < 16; ++i) t += red[i];
+    loss[0] = (float)(t * inv_div);
+  }
+}
+
+// Backward: a workgroup owns 64 columns of the 2048; wavefront q takes rows q, q + 4, ...: gfeat[b][k] = g dlogit[b] w[k]
+// (256 contiguous bytes per row), gw[k] = g sum_b dlogit[b] feat[b][k] summed over the four wavefronts in a fixed
+// order, gb = g sum_b dlogit[b] by workgroup 0.  g = the upstream gradient of the loss scalar (device memory).
+__global__ __launch_bounds__(NT) void dot_sigmoid_bce_bwd_kernel(const float* __restrict__ dlogit, const float* __restrict__ gloss,
+                                                                 const float* __restrict__ feat, const float* __restrict__ w,
+                                                                 float* __restrict__ gfeat, float* __restrict__ gw,
+                                                                 float* __restrict__ gb, int B, int K) {
+  __shared__ float part[NT / 64][64];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  const float g = gloss ? gloss[0] : 1.f;
+  const float wk = k < K ? w[k] : 0.f;
+  float acc = 0.f;
+  for (int b = q; b < B; b += NT / 64) {
+    const float d = g * dlogit[b];
+    if (k < K) {
+      if (gfeat) gfeat[(size_t)b * K + k] = d * wk;
+      if (gw) acc = fmaf(d, feat[(size_t)b * K + k], acc);
+    }
+  }
+  part[q][lane] = acc;
+  __syncthreads();
+  if (q == 0 && gw && k < K) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) t += part[i][lane];
+    gw[k] = t;
+  }
+  if (blockIdx.x == 0 && gb && threadIdx.x == 0) {
+    float t = 0.f;
+    for (int b = 0; b < B; ++b) t += g * dlogit[b];
+    gb[0] = t;
+  }
+}
+
 __global__ __launch_bounds__(NT) void scale_by_scalar_kernel(const float* g, const float* __restrict__ s, float* out,
                                                              size_t n) {
   const float v = s[0];
@@ -250,6 +334,26 @@ extern "C" int vg_bce_loss(const float* p, float target, float* loss, float* gp,
   if (!p || B <= 0 || !(divisor > 0.f)) return VG_ERR_BAD_ARG;
   hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, p, target, (const float*)nullptr, loss, gp, B,
                      1.f / divisor, gscale);
+  VG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vg_dot_sigmoid_bce_fwd(const float* feat, const float* w, const float* bias, float target,
+                                      const float* target_dev, float* p, float* loss, float* dlogit, int B, int K,
+                                      float divisor, void* stream) {
+  if (!feat || !w || !p || B <= 0 || K <= 0 || !(divisor > 0.f)) return VG_ERR_BAD_ARG;
+  if ((K & 3) == 0 && ((((uintptr_t)feat | (uintptr_t)w) & 15) != 0)) return VG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(dot_sigmoid_bce_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, feat, w, bias, target, target_dev,
+                     p, loss, dlogit, B, K, 1.f / divisor);
+  VG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vg_dot_sigmoid_bce_bwd(const float* dlogit, const float* gloss, const float* feat, const float* w,
+                                      float* gfeat, float* gw, float* gb, int B, int K, void* stream) {
+  if (!dlogit || !w || B <= 0 || K <= 0 || (gw && !feat) || (!gfeat && !gw && !gb)) return VG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(dot_sigmoid_bce_bwd_kernel, dim3(cdiv(K, 64)), dim3(NT), 0, (hipStream_t)stream, dlogit, gloss, feat, w,
+                     gfeat, gw, gb, B, K);
   VG_CHECK_LAUNCH();
   return 0;
 }

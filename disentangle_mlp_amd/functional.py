@@ -358,6 +358,31 @@ class BCELossFn(Function):
         return ops.scale_by_scalar(gp, gout.contiguous()), None, None
 
 
+class DotSigmoidBCEFn(Function):
+    """Linear(K -> 1) + Sigmoid + nn.BCELoss against a constant label in one launch each way (model.py:406-408,
+    new_betavaegan.py:101,118,153-154).  Returns (p (B,), loss); p is not differentiable here (the iteration only reads
+    it: mean D(x))."""
+
+    @staticmethod
+    def forward(ctx, feat, w, bias, target, divisor):
+        p, loss, dlogit = ops.dot_sigmoid_bce_fwd(feat, w, bias, target, divisor, want_grad=True)
+        ctx.save_for_backward(feat, w, dlogit)
+        ctx.has_bias = bias is not None
+        ctx.mark_non_differentiable(p)
+        ctx.set_materialize_grads(False)
+        return p, loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, _gp, gloss):
+        if gloss is None:
+            return None, None, None, None, None
+        feat, w, dlogit = ctx.saved_tensors
+        gfeat, gw, gb = ops.dot_sigmoid_bce_bwd(dlogit, gloss.contiguous(), feat, w, ctx.needs_input_grad[0],
+                                                ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        return gfeat, gw, gb, None, None
+
+
 # ------------------------------------------------------------ functional API
 def conv5x5(x, w, bias, stride, bias_grad=BIAS_GRAD_COMPUTE):
     return Conv5x5Fn.apply(x, w, bias, stride, bias_grad)
@@ -419,3 +444,11 @@ def bce_loss(p, label_value, divisor=None):
     if not isinstance(label_value, torch.Tensor):
         label_value = float(label_value)
     return BCELossFn.apply(p.contiguous(), label_value, divisor)
+
+
+def dot_sigmoid_bce(feat, w, bias, label_value, divisor=None):
+    """(p, bce): see DotSigmoidBCEFn.  ``w`` (1, K) or (K,), ``bias`` (1,)."""
+    if not isinstance(label_value, torch.Tensor):
+        label_value = float(label_value)
+    return DotSigmoidBCEFn.apply(feat.contiguous(), w, bias, label_value, divisor)
+

@@ -172,6 +172,9 @@ def shadowed_bias_params(net):
 # CONSUMING convolution while it loads -- the normalised tensor of an inner layer is never written.  False: every
 # BatchNorm runs its own two passes (the round-1 path; tests compare the two).
 FUSE_CONV_BN = True
+# The discriminator's head + BCE as one kernel each way (Discriminator_celeba.forward_with_bce); False /
+# VG_FUSE_HEAD=0: Linear, Sigmoid and the BCE kernel one after the other (A/B timing, tests).
+FUSE_HEAD_BCE = __import__("os").environ.get("VG_FUSE_HEAD", "1") != "0"
 
 
 def _has_hooks(mods):
@@ -343,6 +346,19 @@ class Discriminator_celeba(nn.Module):
         feat = self.lth_features(self.convs(x).view(bs, -1))
         p = self.sigmoid_output(feat)
         return p.squeeze(), feat.squeeze()
+
+    def forward_with_bce(self, x, label, divisor=None):
+        """``forward`` plus ``nn.BCELoss()(p, full(label))`` (new_betavaegan.py:101,118,153-154; ``divisor``: the batch the
+        mean runs over -- the global batch under data parallelism) with the head -- Linear(2048 -> 1) + Sigmoid -- and the
+        loss in ONE kernel each way.  Returns (p, features, bce)."""
+        bs = x.size(0)
+        feat = self.lth_features(self.convs(x).view(bs, -1))
+        lin = self.sigmoid_output[0]
+        if not FUSE_HEAD_BCE or lin._forward_hooks or lin._forward_pre_hooks or self.sigmoid_output[1]._forward_hooks:
+            p = self.sigmoid_output(feat).squeeze()              # hooked head: module by module
+            return p, feat.squeeze(), F.bce_loss(p, label, divisor)
+        p, bce = F.dot_sigmoid_bce(feat, lin.weight, lin.bias, label, divisor)
+        return p, feat.squeeze(), bce
 
 
 class VAE(nn.Module, _DecoderMixin):

@@ -633,6 +633,37 @@ def bce_loss(p, target, divisor=None, gscale=1.0, want_grad=True):
     return loss, gp
 
 
+def dot_sigmoid_bce_fwd(feat, w, bias, target, divisor=None, want_grad=True):
+    """The discriminator's head + its BCE in one launch: p = sigmoid(feat @ w + bias) (B,), the mean BCE of
+    p against ``target`` (float or one-element device tensor) over ``divisor``, and dlogit = d loss / d logit."""
+    lib = _lib.load()
+    _req(feat, "feat"), _req(w, "w")
+    B, K = feat.shape
+    if w.numel() != K:
+        raise RuntimeError("dot_sigmoid_bce: weight does not match the features")
+    p = torch.empty(B, dtype=torch.float32, device=feat.device)
+    loss = torch.empty((), dtype=torch.float32, device=feat.device)
+    dlogit = torch.empty(B, dtype=torch.float32, device=feat.device) if want_grad else None
+    dev = isinstance(target, torch.Tensor)
+    if dev:
+        _req(target, "target")
+    check(lib.vg_dot_sigmoid_bce_fwd(feat.data_ptr(), w.data_ptr(), _ptr(bias), 0.0 if dev else float(target),
+                                     target.data_ptr() if dev else None, p.data_ptr(), loss.data_ptr(), _ptr(dlogit), B, K,
+                                     float(divisor if divisor is not None else B), _stream()), "vg_dot_sigmoid_bce_fwd")
+    return p, loss, dlogit
+
+
+def dot_sigmoid_bce_bwd(dlogit, gloss, feat, w, need_feat=True, need_w=True, need_b=True):
+    lib = _lib.load()
+    B, K = feat.shape
+    gfeat = torch.empty_like(feat) if need_feat else None
+    gw = torch.empty(w.shape, dtype=torch.float32, device=feat.device) if need_w else None
+    gb = torch.empty(1, dtype=torch.float32, device=feat.device) if need_b else None
+    check(lib.vg_dot_sigmoid_bce_bwd(dlogit.data_ptr(), _ptr(gloss), feat.data_ptr(), w.data_ptr(), _ptr(gfeat), _ptr(gw),
+                                     _ptr(gb), B, K, _stream()), "vg_dot_sigmoid_bce_bwd")
+    return gfeat, gw, gb
+
+
 # ---------------------------------------------------------------- image I/O (SURVEY 8f N2 / N3)
 def u8_gather_normalize(images_u8, index, mean=0.5, std=0.5):
     """images_u8 [N,H,W,C] uint8 (device), index int64 (device) -> fp32 [B,C,H,W] =

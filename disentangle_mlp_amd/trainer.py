@@ -529,10 +529,8 @@ class BetaVAEGANTrainer(_GraphedSteps):
         self._zero(netD, self.flat_d)
         fake = netEG.decode(noise)                           # graph kept for phase 2 (:113)
         with F.deferred_wgrad():                             # D runs twice, one backward: big Linear weight gradient once
-            p_real, _ = netD(data)
-            err_real = F.bce_loss(p_real, real_label, gb)
-            p_fake, _ = netD(fake.detach())
-            err_fake = F.bce_loss(p_fake, fake_label, gb)
+            p_real, _, err_real = netD.forward_with_bce(data, real_label, gb)
+            p_fake, _, err_fake = netD.forward_with_bce(fake.detach(), fake_label, gb)
             _backward([err_real, err_fake])
         self._exchange(self.flat_d)
         if grad_hook:
@@ -550,10 +548,8 @@ class BetaVAEGANTrainer(_GraphedSteps):
         with torch.no_grad():
             _, sim_real = netD(data)                         # D fwd #3: BN statistics still update
         recon, mu, logvar = netEG(data, eps2)
-        p_fake2, _ = netD(fake)
-        p_rec, sim_rec = netD(recon)
-        err_g_fake = F.bce_loss(p_fake2, real_label, gb)
-        err_g_rec = F.bce_loss(p_rec, real_label, gb)
+        _, _, err_g_fake = netD.forward_with_bce(fake, real_label, gb)
+        _, sim_rec, err_g_rec = netD.forward_with_bce(recon, real_label, gb)
         sim = F.sim_loss(sim_rec, sim_real)
         mse2 = F.reconstruction_loss(recon, data)
         _backward([err_g_fake, err_g_rec, sim, mse2])
@@ -853,10 +849,8 @@ class GANTrainer(_GraphedSteps):
         self._zero(self.netD, self.flat_d)
         fake = self.netG(noise)
         with F.deferred_wgrad():                             # as BetaVAEGANTrainer's discriminator phase
-            p_real, _ = self.netD(data)
-            err_real = F.bce_loss(p_real, real_label, gb)
-            p_fake, _ = self.netD(fake.detach())
-            err_fake = F.bce_loss(p_fake, fake_label, gb)
+            p_real, _, err_real = self.netD.forward_with_bce(data, real_label, gb)
+            p_fake, _, err_fake = self.netD.forward_with_bce(fake.detach(), fake_label, gb)
             _backward([err_real, err_fake])
         self._exchange(self.flat_d)
         if grad_hook:
@@ -866,8 +860,7 @@ class GANTrainer(_GraphedSteps):
         self._zero(self.netG, self.flat_g)
         for p in self.netD.parameters():
             p.requires_grad_(False)
-        p_fake2, _ = self.netD(fake)
-        err_g = F.bce_loss(p_fake2, real_label, gb)
+        _, _, err_g = self.netD.forward_with_bce(fake, real_label, gb)
         _backward([err_g])
         for p in self.netD.parameters():
             p.requires_grad_(True)

@@ -281,6 +281,19 @@ int vg_bce_loss(const float* p, float target, float* loss, float* gp, int B, flo
 int vg_bce_loss_dev(const float* p, const float* target_dev, float* loss, float* gp, int B, float divisor,
                     float gscale, void* stream);
 
+/* the discriminator's head and its GAN loss in one launch each way -- Linear(2048 -> 1) + Sigmoid
+ * (model.py:406-408) followed by nn.BCELoss against the iteration's label (new_betavaegan.py:101,118,153-154):
+ *   p[b] = sigmoid(<feat[b,:], w> + bias[0]);  loss[0] = the vg_bce_loss of p;
+ *   dlogit[b] = d loss / d logit[b] = (1/divisor) (p-t)/max(p(1-p),1e-12) * p (1-p)      (may be NULL)
+ * (the same fp32 expressions as vg_bias_act_fwd(sigmoid) -> vg_bce_loss -> vg_act_bwd).  The label is `target`, or
+ * target_dev[0] when target_dev != NULL (captured iterations).  Backward, given g = gloss[0] (device; NULL = 1):
+ *   gfeat[b,k] = g dlogit[b] w[k];  gw[k] = g sum_b dlogit[b] feat[b,k];  gb[0] = g sum_b dlogit[b]
+ * (each output may be NULL: a frozen discriminator only relays gfeat). */
+int vg_dot_sigmoid_bce_fwd(const float* feat, const float* w, const float* bias, float target, const float* target_dev,
+                           float* p, float* loss, float* dlogit, int B, int K, float divisor, void* stream);
+int vg_dot_sigmoid_bce_bwd(const float* dlogit, const float* gloss, const float* feat, const float* w, float* gfeat,
+                           float* gw, float* gb, int B, int K, void* stream);
+
 /* ---- Adam (experiments/new_betavaegan.py:49-50: optim.Adam defaults, stepped 3x per iteration)
  * For each tensor: m += (1-beta1)(g-m); v = beta2 v + (1-beta2) g^2;
  * p -= (lr / bias_correction1) * m / (sqrt(v) / bias_correction2_sqrt + eps),

@@ -762,6 +762,28 @@ def test_stats_epilogue_at_the_benchmarked_sizes(H, B, transposed, Cin, Cout, Hs
                                                                 what=f"B={B} fused launch")
 
 
+def test_stats_epilogue_with_a_large_channel_mean(H):
+    """The epilogue's statistics are E[y^2] - mean^2 from fp32 per-wavefront slot sums (64-128 values each) combined in
+    fp64: the slot sums' rounding errors are independent, so over the 512-2048 slots of a B = 128 launch they average
+    out, and the variance stays accurate far beyond |mean| ~ std -- here |mean| / std ~ 50 (a convolution bias of +-50 on
+    unit-variance outputs): 1 / std from the slots within 1e-4 of the two-pass fp64 value (the error
+    grows like (mean / std)^2 * 1e-8 / sqrt(slots); at the O(1) ratios the reference's layers have it is below 1e-7)."""
+    gen = torch.Generator(device="cuda").manual_seed(73)
+    B, Cin, Cout, Hs = 128, 128, 256, 32
+    x = torch.randn(B, Cin, Hs, Hs, device="cuda", generator=gen)
+    w = torch.randn(Cout, Cin, 5, 5, device="cuda", generator=gen) / (Cin * 25) ** 0.5       # unit-variance outputs
+    bias = 50.0 * torch.sign(torch.randn(Cout, device="cuda", generator=gen))
+    y, stats = H.conv5x5_fwd(x, w, bias, 2, want_stats=True)
+    assert stats is not None
+    gamma, beta = torch.ones(Cout, device="cuda"), torch.zeros(Cout, device="cuda")
+    mean, invstd, _, _ = H.bn_finalize_stats(stats, y.numel() // Cout, gamma, beta, None, None, 1e-5, 0.1)
+    yd = y.double()
+    m_ref, v_ref = yd.mean((0, 2, 3)), yd.var((0, 2, 3), unbiased=False)
+    assert 30 < float((m_ref.abs() / v_ref.sqrt()).min())
+    assert_close(mean.cpu(), m_ref.cpu(), 1e-6, "mean")
+    assert_close(invstd.cpu(), (v_ref + 1e-5).rsqrt().cpu(), 1e-4, "1/std at |mean|/std ~ 50")
+
+
 def test_bn_coefficients_from_stats_and_from_pass(H):
     """vg_bn_finalize_stats (slots from a convolution epilogue) and vg_bn_stats (one pass over x) give the
     coefficients, saved statistics and running-statistics update of train-mode batch norm (oracle: F.batch_norm)."""
@@ -874,3 +896,52 @@ def test_thin_kernels_bf16x3(H):
         assert_close(H.conv5x5_wgrad(x3.cuda(), x32.cuda(), 1), gw_ref, 2e-5, "thin wgrad, 2 planes")
     finally:
         H.CONV_ARITH = prev
+
+
+# ------------------------------------------------------------------ K11: discriminator head + BCE in one launch
+@pytest.mark.parametrize("B,K,label,dev_label", [(128, 2048, 0.9, False), (16, 2048, 0.1, True), (5, 70, 0.9, False), (37, 2048, 0.1, False)])
+def test_dot_sigmoid_bce(H, B, K, label, dev_label):
+    """vg_dot_sigmoid_bce_fwd / _bwd (Linear(2048 -> 1) + Sigmoid + nn.BCELoss, model.py:406-408,
+    new_betavaegan.py:101,118,153-154) against the fp64 oracle of the three separate ops: p, the loss and the three
+    gradients; rows whose probability saturates (the -100 clamp of the log, the 1e-12 clamp of p (1 - p)) included;
+    label as a float and as a device scalar; K off the 16-byte path; the autograd Function with a frozen head."""
+    from disentangle_mlp_amd import functional as F
+    g = torch.Generator().manual_seed(95)
+    feat = torch.randn(B, K, generator=g)
+    w = torch.randn(1, K, generator=g) / K ** 0.5
+    bias = torch.randn(1, generator=g)
+    feat[0] *= 60.0                                   # saturate a row each way (|logit| ~ 60: p underflows 1 - p or p)
+    feat[1] *= -60.0
+    fd, wd, bd = feat.double().requires_grad_(), w.double().requires_grad_(), bias.double().requires_grad_()
+    p_ref = torch.sigmoid(fd @ wd.t() + bd).squeeze(1)
+    lab = torch.full((B,), label, dtype=torch.float64)
+    loss_ref = torch.nn.functional.binary_cross_entropy(p_ref, lab)
+    target = torch.tensor([label], device="cuda") if dev_label else label
+    p, loss, dlogit = H.dot_sigmoid_bce_fwd(feat.cuda(), w.cuda(), bias.cuda(), target)
+    ok = (p_ref > 1e-6) & (p_ref < 1 - 1e-6)          # unsaturated rows: tight; saturated ones: the clamps decide
+    assert_close(p.cpu()[ok], p_ref.detach()[ok], 3e-6, "p")
+    # the oracle of the loss follows the fp32 path's clamps: recompute from the kernel's own p in fp64
+    pk = p.double().cpu()
+    loss_k = (-(label * pk.log().clamp(min=-100) + (1 - label) * (1 - pk).log().clamp(min=-100))).mean()
+    assert abs(float(loss) - float(loss_k)) <= 1e-5 * abs(float(loss_k)), (float(loss), float(loss_k))
+    if bool(ok.all()):
+        assert abs(float(loss) - float(loss_ref)) <= 2e-5 * abs(float(loss_ref))
+    gl = torch.tensor(0.75, device="cuda")
+    gfeat, gw, gb = H.dot_sigmoid_bce_bwd(dlogit, gl, feat.cuda(), w.cuda())
+    (0.75 * loss_ref).backward()
+    rows = ok.nonzero().flatten()
+    assert_close(gfeat.cpu()[rows], fd.grad[rows], 1e-5, "gfeat (unsaturated rows)")
+    # saturated rows: BCE's gradient w.r.t. p is clamped at 1e-12 in p (1 - p), the chain through the sigmoid gives
+    # (p - t) p (1 - p) / max(p (1 - p), 1e-12): bounded by |p - t| / B
+    assert float(gfeat.cpu()[~ok].abs().max() if (~ok).any() else 0.0) <= 0.75 * float(w.abs().max()) / B * 1.001
+    if bool(ok.all()):
+        assert_close(gw.cpu(), wd.grad, 1e-5, "gw")
+        assert_close(gb.cpu(), bd.grad, 1e-5, "gb")
+    # the Function: frozen head (a discriminator that only relays gradients) -> only gfeat
+    f2 = feat.cuda().requires_grad_()
+    w2, b2 = w.cuda(), bias.cuda()
+    p2, l2 = F.dot_sigmoid_bce(f2, w2, b2, label, B)
+    assert torch.equal(p2, p) and not p2.requires_grad
+    (l2 * 0.75).backward()
+    assert torch.equal(f2.grad, gfeat)
+
