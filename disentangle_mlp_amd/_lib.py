@@ -69,7 +69,8 @@ SIGNATURES = {
     "vg_adam_prepare": (_I, [ctypes.c_double, _P, _I, ctypes.c_double, ctypes.c_double, ctypes.c_double, _P, _P]),
     "vg_adam_step_dev": (_I, [_P, _I] + [ctypes.c_double] * 3 + [_P, _P]),
     "vg_bce_loss_dev": (_I, [_P, _P, _P, _P, _I, _F, _F, _P]),
-    "vg_dot_sigmoid_bce_fwd": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "vg_dot_sigmoid_bce_workspace_bytes": (_Z, [_I]),
+    "vg_dot_sigmoid_bce_fwd": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _F, _P, _Z, _P]),
     "vg_dot_sigmoid_bce_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "vg_u8_gather_normalize": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
     "vg_minmax_workspace_bytes": (_Z, [_Z]),

@@ -165,70 +165,77 @@ __global__ __launch_bounds__(NT) void bce_kernel(const float* __restrict__ p, fl
 // K11 of SURVEY.md section 2.1: the discriminator's head -- Linear(2048 -> 1) + Sigmoid (model.py:406-408) -- and
 // nn.BCELoss against the iteration's label (new_betavaegan.py:53,101,118,153-154) in ONE launch each way, instead of a
 // GEMV, a sigmoid, a BCE kernel (forward) and a scale, a sigmoid', a bias sum and two GEMMs (backward).
-// Forward: one workgroup of 16 wavefronts; a wavefront owns a row at a time (32 elements per lane as 16-byte loads, one
-// 64-lane shuffle sum), the row terms of the loss are added in a fixed order in double.  Same expressions, in the same
-// fp32 operations, as bias_act (sigmoid), bce_kernel and act_bwd: p, the loss, and dlogit = dBCE/dp * p (1 - p).
+// Forward: a wavefront owns a row (32 elements per lane as 16-byte loads, one 64-lane shuffle sum), 16 rows per
+// workgroup; the row terms of the loss go to the workspace in double and are added in a fixed order by the sum kernel that
+// follows (one workgroup on one CU for the whole 1 MB of features took as long as the three kernels it replaced).  Same
+// expressions, in the same fp32 operations, as bias_act (sigmoid), bce_kernel and act_bwd: p, the loss, and
+// dlogit = dBCE/dp * p (1 - p).
 __global__ __launch_bounds__(1024) void dot_sigmoid_bce_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ w,
                                                                    const float* __restrict__ bias, float target,
                                                                    const float* __restrict__ target_dev,
-                                                                   float* __restrict__ p_out, float* __restrict__ loss,
+                                                                   float* __restrict__ p_out, double* __restrict__ terms,
                                                                    float* __restrict__ dlogit, int B, int K, float inv_div) {
-  __shared__ double red[16];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (target_dev) target = target_dev[0];
   const float b0 = bias ? bias[0] : 0.f;
-  double wave_total = 0.0;
-  for (int b = wid; b < B; b += 16) {
-    const float* row = feat + (size_t)b * K;
-    float s = 0.f;
-    if ((K & 3) == 0) {
-      for (int j = 4 * lane; j < K; j += 256) {
-        const float4 x = *reinterpret_cast<const float4*>(row + j);
-        const float4 v = *reinterpret_cast<const float4*>(w + j);
-        s = fmaf(x.x, v.x, s);
-        s = fmaf(x.y, v.y, s);
-        s = fmaf(x.z, v.z, s);
-        s = fmaf(x.w, v.w, s);
-      }
-    } else {
-      for (int j = lane; j < K; j += 64) s = fmaf(row[j], w[j], s);
+  const int b = blockIdx.x * 16 + wid;                 // one row per wavefront, 16 rows per workgroup
+  if (b >= B) return;
+  const float* row = feat + (size_t)b * K;
+  float s = 0.f;
+  if ((K & 3) == 0) {
+    for (int j = 4 * lane; j < K; j += 256) {
+      const float4 x = *reinterpret_cast<const float4*>(row + j);
+      const float4 v = *reinterpret_cast<const float4*>(w + j);
+      s = fmaf(x.x, v.x, s);
+      s = fmaf(x.y, v.y, s);
+      s = fmaf(x.z, v.z, s);
+      s = fmaf(x.w, v.w, s);
     }
-    s = wave_allsum(s);
+  } else {
+    for (int j = lane; j < K; j += 64) s = fmaf(row[j], w[j], s);
+  }
+  s = wave_allsum(s);
+  if (lane == 0) {
     const float v = 1.f / (1.f + expf(-(s + b0)));
     const float lp = fmaxf(logf(v), -100.f), l1p = fmaxf(logf(1.f - v), -100.f);
-    wave_total += -(double)(target * lp + (1.f - target) * l1p);
-    if (lane == 0) {
-      p_out[b] = v;
-      if (dlogit) dlogit[b] = (inv_div * (v - target) / fmaxf(v * (1.f - v), 1e-12f)) * v * (1.f - v);
-    }
-  }
-  if (lane == 0) red[wid] = wave_total;
-  __syncthreads();
-  if (threadIdx.x == 0 && loss) {
-    double t = 0.0;
-    for (int i = 0; i < 16; ++i) t += red[i];
-    loss[0] = (float)(t * inv_div);
+    p_out[b] = v;
+    terms[b] = -(double)(target * lp + (1.f - target) * l1p);
+    if (dlogit) dlogit[b] = (inv_div * (v - target) / fmaxf(v * (1.f - v), 1e-12f)) * v * (1.f - v);
   }
 }
 
-// Backward: a workgroup owns 64 columns of the 2048; wavefront q takes rows q, q + 4, ...: gfeat[b][k] = g dlogit[b] w[k]
-// (256 contiguous bytes per row), gw[k] = g sum_b dlogit[b] feat[b][k] summed over the four wavefronts in a fixed
-// order, gb = g sum_b dlogit[b] by workgroup 0.  g = the upstream gradient of the loss scalar (device memory).
-__global__ __launch_bounds__(NT) void dot_sigmoid_bce_bwd_kernel(const float* __restrict__ dlogit, const float* __restrict__ gloss,
-                                                                 const float* __restrict__ feat, const float* __restrict__ w,
-                                                                 float* __restrict__ gfeat, float* __restrict__ gw,
-                                                                 float* __restrict__ gb, int B, int K) {
-  __shared__ float part[NT / 64][64];
+// Backward: a workgroup (16 wavefronts) owns 64 columns of the 2048; wavefront q takes rows q, q + 16, ... with four rows'
+// loads in flight: gfeat[b][k] = g dlogit[b] w[k] (256 contiguous bytes per row), gw[k] = g sum_b dlogit[b] feat[b][k]
+// summed over the sixteen wavefronts in a fixed order, gb = g sum_b dlogit[b] by workgroup 0.  g = the upstream gradient
+// of the loss scalar (device memory).  (Four wavefronts walking 32 rows each, one row at a time, took 20 us.)
+constexpr int DSB_NT = 1024, DSB_NW = DSB_NT / 64;
+__global__ __launch_bounds__(DSB_NT) void dot_sigmoid_bce_bwd_kernel(const float* __restrict__ dlogit,
+                                                                     const float* __restrict__ gloss,
+                                                                     const float* __restrict__ feat, const float* __restrict__ w,
+                                                                     float* __restrict__ gfeat, float* __restrict__ gw,
+                                                                     float* __restrict__ gb, int B, int K) {
+  __shared__ float part[DSB_NW][64];
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + lane;
+  const int kc = min(k, K - 1);
   const float g = gloss ? gloss[0] : 1.f;
-  const float wk = k < K ? w[k] : 0.f;
+  const float wk = w[kc];
   float acc = 0.f;
-  for (int b = q; b < B; b += NT / 64) {
-    const float d = g * dlogit[b];
-    if (k < K) {
-      if (gfeat) gfeat[(size_t)b * K + k] = d * wk;
-      if (gw) acc = fmaf(d, feat[(size_t)b * K + k], acc);
+  for (int b0 = q; b0 < B; b0 += 4 * DSB_NW) {
+    float d[4], f[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = min(b0 + u * DSB_NW, B - 1);
+      d[u] = g * dlogit[b];
+      f[u] = gw ? feat[(size_t)b * K + kc] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = b0 + u * DSB_NW;
+      if (b < B && k < K) {
+        if (gfeat) gfeat[(size_t)b * K + k] = d[u] * wk;
+        acc = fmaf(d[u], f[u], acc);
+      }
     }
   }
   part[q][lane] = acc;
@@ -236,13 +243,14 @@ __global__ __launch_bounds__(NT) void dot_sigmoid_bce_bwd_kernel(const float* __
   if (q == 0 && gw && k < K) {
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < NT / 64; ++i) t += part[i][lane];
+    for (int i = 0; i < DSB_NW; ++i) t += part[i][lane];
     gw[k] = t;
   }
-  if (blockIdx.x == 0 && gb && threadIdx.x == 0) {
+  if (blockIdx.x == 0 && gb && q == 1) {           // (a wavefront that is not the one writing gw)
     float t = 0.f;
-    for (int b = 0; b < B; ++b) t += g * dlogit[b];
-    gb[0] = t;
+    for (int b = lane; b < B; b += 64) t += g * dlogit[b];
+    t = wave_allsum(t);
+    if (lane == 0) gb[0] = t;
   }
 }
 
@@ -338,13 +346,20 @@ extern "C" int vg_bce_loss(const float* p, float target, float* loss, float* gp,
   return 0;
 }
 
+extern "C" size_t vg_dot_sigmoid_bce_workspace_bytes(int B) { return B > 0 ? (size_t)B * sizeof(double) : 0; }
+
 extern "C" int vg_dot_sigmoid_bce_fwd(const float* feat, const float* w, const float* bias, float target,
                                       const float* target_dev, float* p, float* loss, float* dlogit, int B, int K,
-                                      float divisor, void* stream) {
-  if (!feat || !w || !p || B <= 0 || K <= 0 || !(divisor > 0.f)) return VG_ERR_BAD_ARG;
+                                      float divisor, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!feat || !w || !p || !loss || B <= 0 || K <= 0 || !(divisor > 0.f)) return VG_ERR_BAD_ARG;
   if ((K & 3) == 0 && ((((uintptr_t)feat | (uintptr_t)w) & 15) != 0)) return VG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(dot_sigmoid_bce_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, feat, w, bias, target, target_dev,
-                     p, loss, dlogit, B, K, 1.f / divisor);
+  if (!workspace || workspace_bytes < vg_dot_sigmoid_bce_workspace_bytes(B)) return VG_ERR_WORKSPACE;
+  double* terms = (double*)workspace;
+  hipLaunchKernelGGL(dot_sigmoid_bce_fwd_kernel, dim3(cdiv(B, 16)), dim3(1024), 0, (hipStream_t)stream, feat, w, bias, target,
+                     target_dev, p, terms, dlogit, B, K, 1.f / divisor);
+  VG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, (const double*)terms, B, loss,
+                     1.f / divisor);
   VG_CHECK_LAUNCH();
   return 0;
 }
@@ -352,8 +367,8 @@ extern "C" int vg_dot_sigmoid_bce_fwd(const float* feat, const float* w, const f
 extern "C" int vg_dot_sigmoid_bce_bwd(const float* dlogit, const float* gloss, const float* feat, const float* w,
                                       float* gfeat, float* gw, float* gb, int B, int K, void* stream) {
   if (!dlogit || !w || B <= 0 || K <= 0 || (gw && !feat) || (!gfeat && !gw && !gb)) return VG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(dot_sigmoid_bce_bwd_kernel, dim3(cdiv(K, 64)), dim3(NT), 0, (hipStream_t)stream, dlogit, gloss, feat, w,
-                     gfeat, gw, gb, B, K);
+  hipLaunchKernelGGL(dot_sigmoid_bce_bwd_kernel, dim3(cdiv(K, 64)), dim3(DSB_NT), 0, (hipStream_t)stream, dlogit, gloss, feat,
+                     w, gfeat, gw, gb, B, K);
   VG_CHECK_LAUNCH();
   return 0;
 }

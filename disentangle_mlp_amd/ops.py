@@ -647,9 +647,11 @@ def dot_sigmoid_bce_fwd(feat, w, bias, target, divisor=None, want_grad=True):
     dev = isinstance(target, torch.Tensor)
     if dev:
         _req(target, "target")
+    ws = workspace(lib.vg_dot_sigmoid_bce_workspace_bytes(B), feat.device)
     check(lib.vg_dot_sigmoid_bce_fwd(feat.data_ptr(), w.data_ptr(), _ptr(bias), 0.0 if dev else float(target),
                                      target.data_ptr() if dev else None, p.data_ptr(), loss.data_ptr(), _ptr(dlogit), B, K,
-                                     float(divisor if divisor is not None else B), _stream()), "vg_dot_sigmoid_bce_fwd")
+                                     float(divisor if divisor is not None else B), ws.data_ptr(), ws.numel(), _stream()),
+          "vg_dot_sigmoid_bce_fwd")
     return p, loss, dlogit
 
 

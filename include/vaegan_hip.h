@@ -281,7 +281,7 @@ int vg_bce_loss(const float* p, float target, float* loss, float* gp, int B, flo
 int vg_bce_loss_dev(const float* p, const float* target_dev, float* loss, float* gp, int B, float divisor,
                     float gscale, void* stream);
 
-/* the discriminator's head and its GAN loss in one launch each way -- Linear(2048 -> 1) + Sigmoid
+/* the discriminator's head and its GAN loss fused (rows kernel + fixed-order sum forward, one kernel backward) -- Linear(2048 -> 1) + Sigmoid
  * (model.py:406-408) followed by nn.BCELoss against the iteration's label (new_betavaegan.py:101,118,153-154):
  *   p[b] = sigmoid(<feat[b,:], w> + bias[0]);  loss[0] = the vg_bce_loss of p;
  *   dlogit[b] = d loss / d logit[b] = (1/divisor) (p-t)/max(p(1-p),1e-12) * p (1-p)      (may be NULL)
@@ -289,8 +289,10 @@ int vg_bce_loss_dev(const float* p, const float* target_dev, float* loss, float*
  * target_dev[0] when target_dev != NULL (captured iterations).  Backward, given g = gloss[0] (device; NULL = 1):
  *   gfeat[b,k] = g dlogit[b] w[k];  gw[k] = g sum_b dlogit[b] feat[b,k];  gb[0] = g sum_b dlogit[b]
  * (each output may be NULL: a frozen discriminator only relays gfeat). */
+size_t vg_dot_sigmoid_bce_workspace_bytes(int B);      /* the row terms of the loss (double), summed in a fixed order */
 int vg_dot_sigmoid_bce_fwd(const float* feat, const float* w, const float* bias, float target, const float* target_dev,
-                           float* p, float* loss, float* dlogit, int B, int K, float divisor, void* stream);
+                           float* p, float* loss, float* dlogit, int B, int K, float divisor,
+                           void* workspace, size_t workspace_bytes, void* stream);
 int vg_dot_sigmoid_bce_bwd(const float* dlogit, const float* gloss, const float* feat, const float* w, float* gfeat,
                            float* gw, float* gb, int B, int K, void* stream);
 
