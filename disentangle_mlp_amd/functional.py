@@ -113,8 +113,9 @@ class LinearFn(Function):
     batched over its passes.  (Round 2's split-bf16 GEMM for these layers was removed: DESIGN.md section 4.5.)"""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w, bias, bias_grad=BIAS_GRAD_COMPUTE):
         ctx.save_for_backward(x, w)
+        ctx.bias_grad = bias_grad
         dctx = getattr(_defer_tls, "current", None)
         ctx.defer = dctx if (dctx is not None and ctx.needs_input_grad[1] and w.numel() >= DEFER_MIN_WEIGHTS) else None
         if ctx.defer is not None:
@@ -129,7 +130,7 @@ class LinearFn(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = gy @ w
-        if ctx.needs_input_grad[2]:
+        if ctx.needs_input_grad[2] and ctx.bias_grad != BIAS_GRAD_ZERO:      # (a bias that feeds a BatchNorm1d: no gradient)
             gb = gy.sum(0)
         if ctx.needs_input_grad[1]:
             wg, wx = gy, x                                   # what the weight gradient is taken over
@@ -145,7 +146,7 @@ class LinearFn(Function):
                         wg, wx = torch.cat([p[0] for p in pairs]), torch.cat([p[1] for p in pairs])
             if wg is not None:
                 gw = wg.t() @ wx
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 class BNActFn(Function):
@@ -392,8 +393,8 @@ def conv_transpose5x5(x, w, bias, stride, bias_grad=BIAS_GRAD_COMPUTE):
     return ConvT5x5Fn.apply(x, w, bias, stride, bias_grad)
 
 
-def linear(x, w, bias):
-    return LinearFn.apply(x.contiguous(), w, bias)
+def linear(x, w, bias, bias_grad=BIAS_GRAD_COMPUTE):
+    return LinearFn.apply(x.contiguous(), w, bias, bias_grad)
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, act=ops.ACT_NONE, stats=None):

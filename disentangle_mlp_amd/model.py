@@ -148,14 +148,22 @@ class HipSigmoid(nn.Module):
 
 class HipLinear(nn.Linear):
     """Linear layer on the vendor fp32 GEMM (hipBLASLt / rocBLAS through torch; trainers load the measured
-    algorithm table of tuned_gemms.py).  Refuses CPU tensors like every other layer here."""
+    algorithm table of tuned_gemms.py).  ``bn_shadowed``: the bias feeds a train-mode BatchNorm1d (x_to_mu.0,
+    x_to_logvar.0, preprocess.0: model.py:461-462, 467-468, 491-492), so its gradient is analytically zero and is defined
+    as exactly zero like the convolution biases' (SURVEY.md section 3.1 item 9).  Refuses CPU tensors like every other
+    layer here."""
+
+    def __init__(self, fin, fout, bn_shadowed=False):
+        super().__init__(fin, fout)
+        self.bn_shadowed = bn_shadowed
 
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("disentangle_mlp_amd modules need CUDA/ROCm tensors (no CPU fallback)")
-        # big layers go through this package's Function: the batched weight gradient of functional.deferred_wgrad()
-        if self.weight.numel() >= F.DEFER_MIN_WEIGHTS and x.dim() == 2:
-            return F.linear(x, self.weight, self.bias)
+        # big layers (and the shadowed ones) go through this package's Function: the batched weight gradient of
+        # functional.deferred_wgrad(), no bias-gradient reduction where it is zero by construction
+        if (self.weight.numel() >= F.DEFER_MIN_WEIGHTS or self.bn_shadowed) and x.dim() == 2:
+            return F.linear(x, self.weight, self.bias, F.BIAS_GRAD_ZERO if self.bn_shadowed else F.BIAS_GRAD_COMPUTE)
         return tF.linear(x, self.weight, self.bias)
 
 
@@ -163,7 +171,7 @@ def shadowed_bias_params(net):
     """The convolution biases whose gradient is defined as exactly zero (they feed a train-mode BatchNorm: HipConv2d /
     HipConvTranspose2d with ``bn_shadowed``): their backward returns no gradient at all, see functional.BIAS_GRAD_ZERO."""
     return [m.bias for m in net.modules()
-            if isinstance(m, (HipConv2d, HipConvTranspose2d)) and m.bn_shadowed and m.bias is not None]
+            if isinstance(m, (HipConv2d, HipConvTranspose2d, HipLinear)) and m.bn_shadowed and m.bias is not None]
 
 
 # --------------------------------------------------------------- building blocks
@@ -251,7 +259,7 @@ def _latent_hw(opt):
 
 
 def _enc_head(width, n_hidden, spatial=(8, 8)):
-    return nn.Sequential(HipLinear(width * 4 * spatial[0] * spatial[1], 2048), HipBatchNorm1d(2048, ops.ACT_RELU),
+    return nn.Sequential(HipLinear(width * 4 * spatial[0] * spatial[1], 2048, bn_shadowed=True), HipBatchNorm1d(2048, ops.ACT_RELU),
                          FusedIntoBN("ReLU"), HipLinear(2048, n_hidden))
 
 
@@ -262,7 +270,7 @@ def _bn_relu(c):
 class _DecoderMixin:
     def _build_decoder(self, n_hidden, n_z):
         dim = n_z[0] * n_z[1] * n_z[2]
-        self.preprocess = nn.Sequential(HipLinear(n_hidden, dim), HipBatchNorm1d(dim, ops.ACT_RELU),
+        self.preprocess = nn.Sequential(HipLinear(n_hidden, dim, bn_shadowed=True), HipBatchNorm1d(dim, ops.ACT_RELU),
                                         FusedIntoBN("ReLU"))
         self.deconv1 = HipConvTranspose2d(n_z[0], 256, 2)
         self.act1 = _bn_relu(256)
