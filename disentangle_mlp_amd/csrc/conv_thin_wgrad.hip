@@ -32,6 +32,11 @@ constexpr int WNT = 512;
 #endif
 
 struct TWArgs {
+  // the gy operand read as act(gy * gy_scale[c] + gy_shift[c]) -- the weight gradient of deconv4 passes the layer's INPUT
+  // in this slot, whose producer's BatchNorm + ReLU is applied here instead of being materialised (NULL: plain)
+  const float* gy_scale;
+  const float* gy_shift;
+  float gy_slope;
   const float* x;
   const float* gy;
   float* slabs;        // [workgroup][Cout][Cin * 25]
@@ -63,6 +68,15 @@ __global__ __launch_bounds__(WNT) void conv_thin_wgrad_kernel(TWArgs A) {
   const int H = A.H, W = A.W, OW = A.OW, OH = A.OH, Cin = A.Cin, Cout = A.Cout;
   const int ng = A.ng, rbi = A.rbi;
   const int row_units = ng * NP, ci_units = rbi * row_units, kw_units = 3 * ci_units;
+
+  const bool aff = A.gy_scale != nullptr;
+  float a_sc[MT], a_sh[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int co = min(m * 32 + l32, Cout - 1);
+    a_sc[m] = aff ? A.gy_scale[co] : 1.f;
+    a_sh[m] = aff ? A.gy_shift[co] : 0.f;
+  }
 
   // ---- per-lane B bases: column n = 32 t + l32 = (ci, kh, kw); columns past Cin * 25 read column 0 (weights unused)
   int bbase[3];
@@ -159,7 +173,16 @@ __global__ __launch_bounds__(WNT) void conv_thin_wgrad_kernel(TWArgs A) {
       const int row = (int)(((float)st + 0.5f) * inv_kg), k16 = st - row * A.kg;
       bf16x8 af[MT][NP];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) split_frag<NP>(raw[slot][m], af[m]);
+      for (int m = 0; m < MT; ++m) {
+        if (aff) {                                     // wave-uniform: a lane's channel is fixed, its coefficients are loaded once
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float v = fmaf(raw[slot][m][j], a_sc[m], a_sh[m]);
+            raw[slot][m][j] = fmaxf(v, 0.f) + A.gy_slope * fminf(v, 0.f);
+          }
+        }
+        split_frag<NP>(raw[slot][m], af[m]);
+      }
       const int boff = (S * row) * row_units + (2 * k16) * NP;
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
@@ -269,14 +292,17 @@ extern "C" size_t vg_conv5x5_thin_wgrad_bf16split_workspace_bytes(int B, int Cin
 
 extern "C" int vg_conv5x5_thin_wgrad_bf16split(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W,
                                                int Cout, int stride, int planes, void* workspace, size_t workspace_bytes,
-                                               void* stream) {
+                                               const float* gy_scale, const float* gy_shift, int gy_act, void* stream) {
   if (!x || !gy || !dw) return VG_ERR_BAD_ARG;
+  if ((gy_scale == nullptr) != (gy_shift == nullptr) || gy_act < VG_ACT_NONE || gy_act > VG_ACT_LRELU) return VG_ERR_BAD_ARG;
   TWPlan p;
   if (!make_twplan(B, Cin, H, W, Cout, stride, planes, p)) return VG_ERR_BAD_ARG;
   if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < p.slab_bytes) return VG_ERR_WORKSPACE;
   if (((uintptr_t)gy & 15) != 0) return VG_ERR_BAD_ARG;
   TWArgs A;
   A.x = x; A.gy = gy; A.slabs = (float*)workspace;
+  A.gy_scale = gy_scale; A.gy_shift = gy_shift;
+  A.gy_slope = (!gy_scale || gy_act == VG_ACT_NONE) ? 1.f : (gy_act == VG_ACT_RELU ? 0.f : 0.2f);
   A.B = B; A.Cin = Cin; A.H = H; A.W = W; A.Cout = Cout; A.OH = p.OH; A.OW = p.OW;
   A.rb = p.rb; A.rbi = p.rbi; A.ng = p.ng; A.kg = p.kg; A.bands = p.bands; A.units_per_wg = p.upw; A.total_units = p.total;
   hipStream_t st = (hipStream_t)stream;

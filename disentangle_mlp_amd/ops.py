@@ -432,20 +432,33 @@ def conv5x5_wgrad(x, gy, stride, out=None, in_affine=None, affine_on_gy=False):
                                                   _planes(), ws.data_ptr(), ws.numel(), _ptr(sc), _ptr(sh), int(act),
                                                   1 if affine_on_gy else 0, _stream()), "vg_conv5x5_wgrad_bf16split")
             return dw
+    if _planes() and THIN_SPLIT and Cin <= 3 and (in_affine is None or affine_on_gy):
+        # <= 3 input channels: one read pass over gy (a producer's BatchNorm + activation applied to it on load: the weight
+        # gradient of the decoder's last layer), x split once per workgroup into shifted plane copies in LDS
+        need = lib.vg_conv5x5_thin_wgrad_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride, _planes())   # 0: shape not taken
+        if need:
+            ws = workspace(need, x.device)
+            sc, sh, act = in_affine if in_affine is not None else (None, None, 0)
+            if sc is not None:
+                _req(sc, "in_scale"), _req(sh, "in_shift")
+            with _timed(("conv_wgrad", B, Cin, H, W, Cout, stride)):
+                check(lib.vg_conv5x5_thin_wgrad_bf16split(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout,
+                                                          stride, _planes(), ws.data_ptr(), ws.numel(), _ptr(sc), _ptr(sh),
+                                                          int(act), _stream()), "vg_conv5x5_thin_wgrad_bf16split")
+            return dw
     if in_affine is not None:      # the kernels below take the operand as a tensor
         if affine_on_gy:
             gy = _materialize(gy, in_affine)
         else:
             x = _materialize(x, in_affine)
     if _planes() and THIN_SPLIT and Cin <= 3:
-        # <= 3 input channels: one read pass over gy, x split once per workgroup into shifted plane copies in LDS
-        need = lib.vg_conv5x5_thin_wgrad_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride, _planes())   # 0: shape not taken
+        need = lib.vg_conv5x5_thin_wgrad_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride, _planes())
         if need:
             ws = workspace(need, x.device)
             with _timed(("conv_wgrad", B, Cin, H, W, Cout, stride)):
                 check(lib.vg_conv5x5_thin_wgrad_bf16split(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout,
-                                                          stride, _planes(), ws.data_ptr(), ws.numel(), _stream()),
-                      "vg_conv5x5_thin_wgrad_bf16split")
+                                                          stride, _planes(), ws.data_ptr(), ws.numel(), None, None, 0,
+                                                          _stream()), "vg_conv5x5_thin_wgrad_bf16split")
             return dw
     need = lib.vg_conv5x5_wgrad_workspace_bytes(B, Cin, H, W, Cout, stride)
     ws = workspace(need, x.device)

@@ -169,7 +169,11 @@ int vg_conv5x5_thin_bf16split(const float* x, const float* w, const float* bias,
  * not a multiple of 16, ...): use vg_conv5x5_wgrad then.  workspace: 16-byte aligned; gy 16-byte aligned. */
 size_t vg_conv5x5_thin_wgrad_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride, int planes);
 int vg_conv5x5_thin_wgrad_bf16split(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W, int Cout,
-                                    int stride, int planes, void* workspace, size_t workspace_bytes, void* stream);
+                                    int stride, int planes, void* workspace, size_t workspace_bytes,
+                                    /* gy read as act(gy * gy_scale[c] + gy_shift[c]) (NULL, NULL, 0: plain): the weight
+                                     * gradient of ConvTranspose2d(32, 3) passes the layer's input here, the train-mode
+                                     * BatchNorm + ReLU of its producer (model.py:505) is applied on load */
+                                    const float* gy_scale, const float* gy_shift, int gy_act, void* stream);
 /* vg_conv5x5_wgrad in the same arithmetic.  The reduction runs over images in groups of 16: gy is re-laid
  * batch-innermost inside the call (B zero-padded to a multiple of 16), x is staged straight from NCHW; needs
  * OW % 8 == 0 -- the workspace query returns 0 for shapes it does not take (use vg_conv5x5_wgrad).

@@ -882,6 +882,34 @@ def test_conv_thin_wgrad_split(H, B, Cin, Cout, Hs, Ws, stride):
     assert torch.equal(gw, H.conv5x5_wgrad(x.cuda(), gy.cuda(), stride))
 
 
+@pytest.mark.parametrize("B,Hs,Ws,act", [(3, 64, 64, 1), (2, 21, 48, 2), (128, 64, 64, 1)])
+def test_conv_thin_wgrad_with_affine_on_the_wide_operand(H, B, Hs, Ws, act):
+    """The weight gradient of the decoder's last layer, ConvTranspose2d(32, 3, 5, 1, 2) (model.py:507): the 3-channel
+    kernel with the roles swapped takes the layer's 32-channel INPUT in its gy slot and applies the producer's
+    BatchNorm + activation to it on load (vg_conv5x5_thin_wgrad_bf16split, gy_scale / gy_shift) instead of reading a
+    materialised copy -- against the fp64 oracle of the materialised computation; B = 128: the benchmark's launch, checked
+    against the materialising path of the same kernel (device vs device) and on one image against the oracle."""
+    g = torch.Generator().manual_seed(96)
+    x = torch.randn(B, 32, Hs, Ws, generator=g)                # the layer's input (pre-BatchNorm)
+    gy = torch.randn(B, 3, Hs, Ws, generator=g)                # gradient of the layer's 3-channel output
+    scale, shift = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g)
+    aff = (scale.cuda(), shift.cuda(), act)
+    gw = H.conv5x5_wgrad(gy.cuda(), x.cuda(), 1, in_affine=aff, affine_on_gy=True)
+    assert gw.shape == (32, 3, 5, 5)
+    tol = CONV_TOL if os.environ.get("VG_CONV_ARITH", "bf16x6") != "bf16x3" else 2e-5
+    if B <= 8:
+        xa = x.double() * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+        xa = xa.clamp(min=0) if act == 1 else torch.where(xa > 0, xa, 0.2 * xa)
+        _, gw_ref = O.convT5x5_grads(xa, torch.zeros(32, 3, 5, 5), gy, 1)
+        assert_close(gw, gw_ref, tol, "thin wgrad, BatchNorm + activation on load")
+    else:
+        xm = H.affine_act(x.cuda(), *aff)
+        assert_close(gw, H.conv5x5_wgrad(gy.cuda(), xm, 1).double().cpu(), 2e-6, "on load vs materialised")
+        xa = x[:1].double() * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+        _, gw_ref = O.convT5x5_grads(xa.clamp(min=0), torch.zeros(32, 3, 5, 5), gy[:1], 1)
+        assert_close(H.conv5x5_wgrad(gy[:1].cuda(), x[:1].cuda(), 1, in_affine=aff, affine_on_gy=True), gw_ref, tol, "one image")
+
+
 def test_thin_kernels_bf16x3(H):
     """The three 3-channel kernels with two planes (the opt-in bf16x3 arithmetic): 2e-5 against the fp64 oracle."""
     g = torch.Generator().manual_seed(93)
