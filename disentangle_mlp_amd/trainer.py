@@ -352,6 +352,29 @@ class _GraphedSteps:
         self._graphs, self._shape_steps = {}, {}
         return self.graph
 
+    _pack_plans = None
+
+    def _run_with_pack_plan(self, body, nets):
+        """``body(prepack)`` is one iteration; ``prepack(name)`` re-packs, in ONE launch, every split-bf16 filter of network
+        ``name`` (None: of all networks) that the trainer's convolutions are known to ask for -- to be called at the start
+        of the iteration and after each optimizer step.  The first iteration only records what is asked for (the filters
+        are packed one by one on first use, as without a plan)."""
+        if self._pack_plans is None:
+            with ops.record_pack_requests() as rec:
+                out = body(lambda name=None: None)
+            owner = {p.data_ptr(): name for name, net in nets.items() for p in net.parameters()}
+            seen, plans = set(), {name: [] for name in nets}
+            for r in rec.requests:
+                k = (r[0].data_ptr(), r[3], r[4])
+                if k not in seen and r[0].data_ptr() in owner:
+                    seen.add(k)
+                    plans[owner[r[0].data_ptr()]].append(r)
+            self._pack_plans = plans
+            return out
+        plans = self._pack_plans
+        return body(lambda name=None: ops.prepack_filters(plans[name] if name is not None
+                                                          else [r for v in plans.values() for r in v]))
+
     def _graph_usable(self, optimizers, data, grad_hook):
         return (self.graph and grad_hook is None and ops._timing is None and data.is_cuda
                 and all(isinstance(o, HipAdam) and o.device_scalars for o in optimizers)
@@ -432,7 +455,6 @@ class BetaVAEGANTrainer(_GraphedSteps):
         self._eg_params = [p for p in self.netEG.parameters() if p.dim() == 4]   # convolution filters
         self._d_params = [p for p in self.netD.parameters() if p.dim() == 4]
         self.rank = _dist_rank()
-        self._pack_plan = None
         self.latent_generator = _latent_generator(self.device, seed, self.rank)
         self.label_rng = _shared_label_rng(seed)          # used by train_epoch when world > 1: one draw per GLOBAL batch
 
@@ -499,27 +521,15 @@ class BetaVAEGANTrainer(_GraphedSteps):
             eps2 = self.draw_latents(B)
         if eps3 is None:
             eps3 = self.draw_latents(B)
-        # Packed filters: the first iteration records which (weight, layout) pairs its convolutions ask for; from then
-        # on all filters a network's optimizer step has changed are re-packed in ONE launch (32 launches -> 3)
-        plan = self._pack_plan
-        if plan is None:
-            with ops.record_pack_requests() as rec:
-                out = self._step_body(data, noise, eps2, eps3, real_label, fake_label, global_batch, grad_hook, None)
-            d_ptrs = {p.data_ptr() for p in netD.parameters()}
-            seen, self._pack_plan = set(), {"d": [], "eg": []}
-            for r in rec.requests:
-                k = (r[0].data_ptr(), r[3], r[4])
-                if k not in seen:
-                    seen.add(k)
-                    self._pack_plan["d" if r[0].data_ptr() in d_ptrs else "eg"].append(r)
-            return out
-        return self._step_body(data, noise, eps2, eps3, real_label, fake_label, global_batch, grad_hook, plan)
+        # Packed filters: all filters an optimizer step has changed are re-packed in ONE launch (32 launches -> 3)
+        return self._run_with_pack_plan(
+            lambda prepack: self._step_body(data, noise, eps2, eps3, real_label, fake_label, global_batch, grad_hook, prepack),
+            {"d": netD, "eg": netEG})
 
-    def _step_body(self, data, noise, eps2, eps3, real_label, fake_label, global_batch, grad_hook, plan):
+    def _step_body(self, data, noise, eps2, eps3, real_label, fake_label, global_batch, grad_hook, prepack):
         netEG, netD = self.netEG, self.netD
         B = data.size(0)
-        if plan is not None:
-            ops.prepack_filters(plan["d"] + plan["eg"])
+        prepack()
         # BCE is a mean over the GLOBAL batch (DataParallel gathers the outputs before the loss); equal
         # shards are assumed unless the caller says otherwise (train_epoch passes the loader's count)
         gb = global_batch if global_batch is not None else B * self.world
@@ -537,8 +547,7 @@ class BetaVAEGANTrainer(_GraphedSteps):
             grad_hook("D", netD)
         self.optimizerD.step()
         ops.invalidate_packed_filters(self._d_params)
-        if plan is not None:
-            ops.prepack_filters(plan["d"])
+        prepack("d")
         out["errD_real"], out["errD_fake"] = err_real.detach(), err_fake.detach()
         out["D_x_sum"] = p_real.detach().sum()
 
@@ -559,8 +568,7 @@ class BetaVAEGANTrainer(_GraphedSteps):
             grad_hook("EG2", netEG)
         self.optimizerEG.step()
         ops.invalidate_packed_filters(self._eg_params)
-        if plan is not None:
-            ops.prepack_filters(plan["eg"])
+        prepack("eg")
         out.update(errG_fake=err_g_fake.detach(), errG_recon=err_g_rec.detach(), sim=sim.detach(),
                    mse_dec=mse2.detach())
 
@@ -750,6 +758,10 @@ class VAETrainer(_GraphedSteps):
     def _step(self, data, eps):
         if eps is None:                       # model.py:534, from this replica's own stream
             eps = torch.randn(data.size(0), self.opt.n_hidden, device=self.device, generator=self.latent_generator)
+        return self._run_with_pack_plan(lambda prepack: self._step_body(data, eps, prepack), {"vae": self.model})
+
+    def _step_body(self, data, eps, prepack):
+        prepack()                             # the filters the previous optimizer step changed: one pack launch
         if self.flat is not None:
             self.flat.zero_and_attach()
         else:
@@ -842,10 +854,16 @@ class GANTrainer(_GraphedSteps):
                                  (self.netG, self.netD), eager)
 
     def _step(self, data, noise, real_label, fake_label, global_batch, grad_hook):
-        B = data.size(0)
         if noise is None:
-            noise = torch.randn(B, self.opt.n_hidden, device=self.device, generator=self.latent_generator)
+            noise = torch.randn(data.size(0), self.opt.n_hidden, device=self.device, generator=self.latent_generator)
+        return self._run_with_pack_plan(
+            lambda prepack: self._step_body(data, noise, real_label, fake_label, global_batch, grad_hook, prepack),
+            {"d": self.netD, "g": self.netG})
+
+    def _step_body(self, data, noise, real_label, fake_label, global_batch, grad_hook, prepack):
+        B = data.size(0)
         gb = global_batch if global_batch is not None else B * self.world
+        prepack()
         self._zero(self.netD, self.flat_d)
         fake = self.netG(noise)
         with F.deferred_wgrad():                             # as BetaVAEGANTrainer's discriminator phase
@@ -856,7 +874,8 @@ class GANTrainer(_GraphedSteps):
         if grad_hook:
             grad_hook("D", self.netD)
         self.optimizerD.step()
-        ops.invalidate_packed_filters()
+        ops.invalidate_packed_filters([p for p in self.netD.parameters() if p.dim() == 4])
+        prepack("d")
         self._zero(self.netG, self.flat_g)
         for p in self.netD.parameters():
             p.requires_grad_(False)
