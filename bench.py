@@ -16,6 +16,13 @@ Synthetic data (U(-1,1) images, N(0,1) noise; each rank its own shard) resident 
 before the timed region; weights from the reference's seed recipe.  Prints ONE JSON line
 on rank 0.
 
+On one GPU the timed steps are replays of ONE HIP graph of the whole iteration (trainer._CapturedIteration: captured
+during untimed preparation, bit-identical to eager stepping; ``launch_mode`` in the line says which it was; VG_GRAPH=0
+forces eager).  Launches inside a replayed graph cannot be bracketed by events, so the dominant kernel of ``roofline`` is
+timed in an eager leg of the same K iterations right after the timed region (``roofline.launches_timed_in``).  Under
+N > 1 the iteration stays eager (the gradient exchange is launched from autograd hooks) and the line carries
+``data_parallel``: ranks the transport connected, bytes all-reduced and time the compute stream waited per step.
+
 ``--rehearse-launch``: the same launch path without a GPU -- every rank joins a gloo group,
 the world is checked with an all-reduce and rank 0 prints a line marked "rehearsal" (no
 throughput is measured or reported).  ``VG_DIST_BACKEND=gloo`` runs the real benchmark with
