@@ -41,20 +41,20 @@ SIGNATURES = {
     "vg_convT5x5_fwd_bf16split_stats_floats": (_Z, [_I, _I, _I, _I, _I, _I]),
     "vg_convT5x5_s1_thin_bf16split_ok": (_I, [_I, _I, _I, _I]),
     "vg_conv5x5_thin_wgrad_bf16split_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
-    "vg_conv5x5_thin_wgrad_bf16split": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _I, _P]),
+    "vg_conv5x5_thin_wgrad_bf16split": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _I, _I, _P]),
     "vg_conv5x5_thin_bf16split_ok": (_I, [_I, _I, _I, _I, _I]),
     "vg_conv5x5_thin_bf16split_stats_floats": (_Z, [_I, _I, _I, _I, _I, _I]),
     "vg_conv5x5_thin_bf16split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "vg_convT5x5_s1_thin_bf16split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "vg_conv5x5_fwd_bf16split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P]),
     "vg_conv5x5_wgrad_bf16split_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
-    "vg_conv5x5_wgrad_bf16split": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _I, _I, _P]),
+    "vg_conv5x5_wgrad_bf16split": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _I, _I, _I, _P]),
     "vg_conv5x5_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
-    "vg_conv5x5_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "vg_conv5x5_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _I, _P]),
     "vg_channel_sum": (_I, [_P, _P, _I, _I, _I, _P, _Z, _P]),
     "vg_bn_workspace_bytes": (_Z, [_I]),
     "vg_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P, _Z, _P]),
-    "vg_bn_act_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
+    "vg_bn_act_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "vg_bn_finalize_stats": (_I, [_P, _I, _I, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _Z, _P]),
     "vg_bn_stats": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _Z, _P]),
     "vg_affine_act": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -72,7 +72,7 @@ SIGNATURES = {
     "vg_bce_loss_dev": (_I, [_P, _P, _P, _P, _I, _F, _F, _P]),
     "vg_dot_sigmoid_bce_workspace_bytes": (_Z, [_I]),
     "vg_dot_sigmoid_bce_fwd": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _F, _P, _Z, _P]),
-    "vg_dot_sigmoid_bce_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "vg_dot_sigmoid_bce_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vg_u8_gather_normalize": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
     "vg_minmax_workspace_bytes": (_Z, [_Z]),
     "vg_minmax": (_I, [_P, _Z, _P, _P, _Z, _P]),

@@ -130,6 +130,8 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
                                                       float* __restrict__ running_var, float* __restrict__ dgamma,
                                                       float* __restrict__ dbeta, float* __restrict__ out, int B,
                                                       int C, int HW, long per, float eps, float momentum, int act) {
+  const bool accp = (act & 0x100) != 0;        // backward: dgamma / dbeta are accumulated into (bit 8 of `act`)
+  act &= 0xff;
   // `per`: elements of this channel per workgroup of THIS pass (independent of the partial pass)
   __shared__ float s_co[4];
   const int c = blockIdx.x, k = blockIdx.y;
@@ -166,9 +168,9 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
         s_co[1] = beta[c] - mu * sc;
         s_co[2] = (float)(s1 / count);
         s_co[3] = (float)(s2 / count);
-        if (k == 0) {
-          if (dbeta) dbeta[c] = (float)s1;
-          if (dgamma) dgamma[c] = (float)s2;
+        if (k == 0) {       // accp: added to what is there (a layer used twice before one backward: no add launch)
+          if (dbeta) dbeta[c] = (float)s1 + (accp ? dbeta[c] : 0.f);
+          if (dgamma) dgamma[c] = (float)s2 + (accp ? dgamma[c] : 0.f);
         }
       }
     }
@@ -279,6 +281,8 @@ __global__ __launch_bounds__(NT) void bn1d_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ invstd, float* __restrict__ gx,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int B,
                                                       int C, int act) {
+  const bool accp = (act & 0x100) != 0;        // as bn_apply_kernel
+  act &= 0xff;
   __shared__ double r1[B1_SL][B1_CH], r2[B1_SL][B1_CH];
   __shared__ float s_c1[B1_CH], s_c2[B1_CH];
   const int cl = threadIdx.x % B1_CH, sl = threadIdx.x / B1_CH;
@@ -309,8 +313,8 @@ __global__ __launch_bounds__(NT) void bn1d_bwd_kernel(const float* __restrict__ 
       t1 += r1[k][cl];
       t2 += r2[k][cl];
     }
-    if (dbeta) dbeta[c] = (float)t1;
-    if (dgamma) dgamma[c] = (float)t2;
+    if (dbeta) dbeta[c] = (float)t1 + (accp ? dbeta[c] : 0.f);
+    if (dgamma) dgamma[c] = (float)t2 + (accp ? dgamma[c] : 0.f);
     s_c1[cl] = (float)(t1 / B);
     s_c2[cl] = (float)(t2 / B);
   }
@@ -640,15 +644,16 @@ extern "C" int vg_bn_act_fwd(const float* x, const float* gamma, const float* be
 
 extern "C" int vg_bn_act_bwd(const float* gy, const float* x, const float* gamma, const float* beta,
                              const float* save_mean, const float* save_invstd, float* gx, float* dgamma,
-                             float* dbeta, int B, int C, int HW, int act, void* workspace, size_t workspace_bytes,
-                             void* stream) {
+                             float* dbeta, int B, int C, int HW, int act, int accumulate_param_grads, void* workspace,
+                             size_t workspace_bytes, void* stream) {
   if (!gy || !x || !gamma || !beta || !save_mean || !save_invstd || !gx || B <= 0 || C <= 0 || HW <= 0)
     return VG_ERR_BAD_ARG;
   if (act < VG_ACT_NONE || act > VG_ACT_LRELU) return VG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
+  const int act_apply = act | (accumulate_param_grads ? 0x100 : 0);      // bit 8: dgamma / dbeta += (kernels decode it)
   if (HW == 1) {
     hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(cdiv(C, B1_CH)), dim3(NT), 0, st, gy, x, gamma, beta, save_mean,
-                       save_invstd, gx, dgamma, dbeta, B, C, act);
+                       save_invstd, gx, dgamma, dbeta, B, C, act_apply);
     VG_CHECK_LAUNCH();
     return 0;
   }
@@ -661,7 +666,7 @@ extern "C" int vg_bn_act_bwd(const float* gy, const float* x, const float* gamma
   const Slicing a = make_apply_slicing(B, C, HW);
   hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(C, a.ns), dim3(NT), 0, st, x, gy, (const double*)part, s.ns, gamma,
                      beta, const_cast<float*>(save_mean), const_cast<float*>(save_invstd), (float*)nullptr,
-                     (float*)nullptr, dgamma, dbeta, gx, B, C, HW, a.per, 0.f, 0.f, act);
+                     (float*)nullptr, dgamma, dbeta, gx, B, C, HW, a.per, 0.f, 0.f, act_apply);
   VG_CHECK_LAUNCH();
   return 0;
 }

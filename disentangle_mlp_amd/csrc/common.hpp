@@ -71,7 +71,7 @@ __device__ __forceinline__ T block_sum(T v, T* red) {
 __host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // cross-file internal entry points (not part of the C ABI)
-int vg_internal_wgrad_reduce(const float* slabs, float* dw, int n, int splits, hipStream_t st);
+int vg_internal_wgrad_reduce(const float* slabs, float* dw, int n, int splits, hipStream_t st, int accumulate = 0);
 // conv_ring.hip: stride-2 split-bf16 convolution (mode 0) / transposed convolution (mode 1), 8-wave ring kernel
 size_t vg_internal_ring_workspace_bytes(int mode, int B, int Cin, int H, int W, int Cout);
 size_t vg_internal_ring_stats_floats(int mode, int B, int Cin, int H, int W, int Cout);

@@ -292,7 +292,8 @@ extern "C" size_t vg_conv5x5_thin_wgrad_bf16split_workspace_bytes(int B, int Cin
 
 extern "C" int vg_conv5x5_thin_wgrad_bf16split(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W,
                                                int Cout, int stride, int planes, void* workspace, size_t workspace_bytes,
-                                               const float* gy_scale, const float* gy_shift, int gy_act, void* stream) {
+                                               const float* gy_scale, const float* gy_shift, int gy_act, int accumulate,
+                                               void* stream) {
   if (!x || !gy || !dw) return VG_ERR_BAD_ARG;
   if ((gy_scale == nullptr) != (gy_shift == nullptr) || gy_act < VG_ACT_NONE || gy_act > VG_ACT_LRELU) return VG_ERR_BAD_ARG;
   TWPlan p;
@@ -310,5 +311,5 @@ extern "C" int vg_conv5x5_thin_wgrad_bf16split(const float* x, const float* gy, 
   if (stride == 1) rc = p.mt == 1 ? launch_tw<1, 1>(A, p, planes, st) : launch_tw<1, 2>(A, p, planes, st);
   else rc = p.mt == 1 ? launch_tw<2, 1>(A, p, planes, st) : launch_tw<2, 2>(A, p, planes, st);
   if (rc) return rc;
-  return vg_internal_wgrad_reduce(A.slabs, dw, Cout * Cin * 25, p.wgs, st);
+  return vg_internal_wgrad_reduce(A.slabs, dw, Cout * Cin * 25, p.wgs, st, accumulate ? 1 : 0);
 }

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv5x5_wgrad_kernel(WArgs A) {
 // where a small filter was split hundreds of ways (few workgroups: the slab chain is the latency).
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
-                                                              int n, int splits) {
+                                                              int n, int splits, int accumulate) {
   __shared__ float red[NW][64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
@@ -267,7 +267,8 @@ __global__ __launch_bounds__(64 * NW) void wgrad_reduce_kernel(const float* __re
     if (wid < w) red[wid][lane] += red[wid + w][lane];
     __syncthreads();
   }
-  if (wid == 0 && i < n) dw[i] = red[0][lane] + red[1][lane];
+  // accumulate: added to what dw holds (a filter used twice before one backward: no separate add launch)
+  if (wid == 0 && i < n) dw[i] = (red[0][lane] + red[1][lane]) + (accumulate ? dw[i] : 0.f);
 }
 
 struct Plan {
@@ -336,11 +337,11 @@ int dispatch_tw(const WArgs& A, int tw, int tm, int cit, hipStream_t st) {
 }  // namespace
 
 // shared with wgrad_bf16split.hip: dw[i] = sum over `splits` slabs of n floats, fixed order
-int vg_internal_wgrad_reduce(const float* slabs, float* dw, int n, int splits, hipStream_t st) {
+int vg_internal_wgrad_reduce(const float* slabs, float* dw, int n, int splits, hipStream_t st, int accumulate) {
   if (splits >= 64 && cdiv(n, 64) < 1024)
-    hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(cdiv(n, 64)), dim3(1024), 0, st, slabs, dw, n, splits);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(cdiv(n, 64)), dim3(1024), 0, st, slabs, dw, n, splits, accumulate);
   else
-    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(cdiv(n, 64)), dim3(256), 0, st, slabs, dw, n, splits);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(cdiv(n, 64)), dim3(256), 0, st, slabs, dw, n, splits, accumulate);
   VG_CHECK_LAUNCH();
   return 0;
 }
@@ -365,7 +366,8 @@ extern "C" size_t vg_conv5x5_wgrad_workspace_bytes(int B, int Cin, int H, int W,
 }
 
 extern "C" int vg_conv5x5_wgrad(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W,
-                                int Cout, int stride, void* workspace, size_t workspace_bytes, void* stream) {
+                                int Cout, int stride, void* workspace, size_t workspace_bytes, int accumulate,
+                                void* stream) {
   if (!x || !gy || !dw || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return VG_ERR_BAD_ARG;
   if (stride != 1 && stride != 2) return VG_ERR_BAD_ARG;
   const Plan p = make_plan(B, Cin, H, W, Cout, stride);
@@ -380,5 +382,5 @@ extern "C" int vg_conv5x5_wgrad(const float* x, const float* gy, float* dw, int 
   A.vec4 = (p.OW % 4 == 0 && ((uintptr_t)gy & 15) == 0 && g_wgrad_vec4) ? 1 : 0;
   int rc = (stride == 2) ? dispatch_tw<2>(A, p.tw, p.tm, p.cit, st) : dispatch_tw<1>(A, p.tw, p.tm, p.cit, st);
   if (rc) return rc;
-  return vg_internal_wgrad_reduce((const float*)workspace, dw, Cout * Cin * 25, p.splits, st);
+  return vg_internal_wgrad_reduce((const float*)workspace, dw, Cout * Cin * 25, p.splits, st, accumulate ? 1 : 0);
 }

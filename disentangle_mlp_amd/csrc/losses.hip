@@ -213,7 +213,7 @@ __global__ __launch_bounds__(DSB_NT) void dot_sigmoid_bce_bwd_kernel(const float
                                                                      const float* __restrict__ gloss,
                                                                      const float* __restrict__ feat, const float* __restrict__ w,
                                                                      float* __restrict__ gfeat, float* __restrict__ gw,
-                                                                     float* __restrict__ gb, int B, int K) {
+                                                                     float* __restrict__ gb, int B, int K, int accumulate) {
   __shared__ float part[DSB_NW][64];
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + lane;
@@ -244,13 +244,13 @@ __global__ __launch_bounds__(DSB_NT) void dot_sigmoid_bce_bwd_kernel(const float
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < DSB_NW; ++i) t += part[i][lane];
-    gw[k] = t;
+    gw[k] = t + (accumulate ? gw[k] : 0.f);      // accumulate: the head is used twice before one backward
   }
   if (blockIdx.x == 0 && gb && q == 1) {           // (a wavefront that is not the one writing gw)
     float t = 0.f;
     for (int b = lane; b < B; b += 64) t += g * dlogit[b];
     t = wave_allsum(t);
-    if (lane == 0) gb[0] = t;
+    if (lane == 0) gb[0] = t + (accumulate ? gb[0] : 0.f);
   }
 }
 
@@ -365,10 +365,11 @@ extern "C" int vg_dot_sigmoid_bce_fwd(const float* feat, const float* w, const f
 }
 
 extern "C" int vg_dot_sigmoid_bce_bwd(const float* dlogit, const float* gloss, const float* feat, const float* w,
-                                      float* gfeat, float* gw, float* gb, int B, int K, void* stream) {
+                                      float* gfeat, float* gw, float* gb, int B, int K, int accumulate_param_grads,
+                                      void* stream) {
   if (!dlogit || !w || B <= 0 || K <= 0 || (gw && !feat) || (!gfeat && !gw && !gb)) return VG_ERR_BAD_ARG;
   hipLaunchKernelGGL(dot_sigmoid_bce_bwd_kernel, dim3(cdiv(K, 64)), dim3(DSB_NT), 0, (hipStream_t)stream, dlogit, gloss, feat,
-                     w, gfeat, gw, gb, B, K);
+                     w, gfeat, gw, gb, B, K, accumulate_param_grads ? 1 : 0);
   VG_CHECK_LAUNCH();
   return 0;
 }

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
 
 // dw[e] = sum of the pieces of e's output tile, in workgroup order (fixed: the result does not depend on timing)
 __global__ __launch_bounds__(256) void wx_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int Cin,
-                                                       int tco, int mtiles, int chunks, int upw, unsigned n) {
+                                                       int tco, int mtiles, int chunks, int upw, unsigned n, int accumulate) {
   const unsigned e = blockIdx.x * 256u + threadIdx.x;
   if (e >= n) return;
   const int row = Cin * 25, co = e / row, ci = (e - co * row) / 25;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void wx_reduce_kernel(const float* __restrict_
     for (int k = 0; k < 4; ++k) sum += v[k];
   }
   for (; p < cnt; ++p) sum += slabs[(size_t)p * n + e];
-  dw[e] = sum;
+  dw[e] = sum + (accumulate ? dw[e] : 0.f);        // accumulate: see wgrad_reduce_kernel
 }
 
 struct XPlan {
@@ -491,7 +491,7 @@ extern "C" size_t vg_conv5x5_wgrad_bf16split_workspace_bytes(int B, int Cin, int
 extern "C" int vg_conv5x5_wgrad_bf16split(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W,
                                        int Cout, int stride, int planes, void* workspace, size_t workspace_bytes,
                                        const float* in_scale, const float* in_shift, int in_act, int affine_on_gy,
-                                       void* stream) {
+                                       int accumulate, void* stream) {
   if (!x || !gy || !dw || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return VG_ERR_BAD_ARG;
   if ((in_scale == nullptr) != (in_shift == nullptr) || in_act < VG_ACT_NONE || in_act > VG_ACT_LRELU) return VG_ERR_BAD_ARG;
   const float slope = (!in_scale || in_act == VG_ACT_NONE) ? 1.f : (in_act == VG_ACT_RELU ? 0.f : 0.2f);
@@ -527,7 +527,7 @@ extern "C" int vg_conv5x5_wgrad_bf16split(const float* x, const float* gy, float
   if (rc) return rc;
   const unsigned n = (unsigned)Cout * Cin * 25;
   hipLaunchKernelGGL(wx_reduce_kernel, dim3(cdiv(n, 256u)), dim3(256), 0, st, slabs, dw, Cin, 32 * p.wco, p.mtiles,
-                     p.chunks, p.upw, n);
+                     p.chunks, p.upw, n, accumulate ? 1 : 0);
   VG_CHECK_LAUNCH();
   return 0;
 }

@@ -103,6 +103,52 @@ class deferred_wgrad:
         return False
 
 
+_acc_tls = __import__("threading").local()
+
+
+class accumulate_param_grads:
+    """Context for iterations that apply a layer several times before ONE backward (the discriminator on the real and on
+    the generated batch, the decoder on the prior sample and on the reconstruction: new_betavaegan.py:99-121, 144-163).
+    The first backward pass through a layer hands autograd its parameter gradient as usual and remembers the tensor; a
+    later pass ADDS into that tensor inside its own kernel (`accumulate` of vg_conv5x5_wgrad*, vg_bn_act_bwd,
+    vg_dot_sigmoid_bce_bwd, addmm_ for Linear) and hands autograd nothing -- instead of a second tensor plus the addition
+    autograd would launch (29 of them per iteration).  Floating-point addition is commutative: same bits as autograd's sum.
+    Forward passes capture the context object; `reset()` forgets the remembered tensors (call it where gradients are
+    zeroed: a new backward must not add into the previous one's tensors).  Outside a context nothing changes."""
+
+    def __init__(self):
+        self.acc, self.open = {}, False
+
+    def __enter__(self):
+        self._outer = getattr(_acc_tls, "current", None)
+        _acc_tls.current = self
+        self.open = True
+        return self
+
+    def __exit__(self, *exc):
+        _acc_tls.current = self._outer
+        self.open, self.acc = False, {}
+        return False
+
+    def reset(self):
+        self.acc = {}
+
+
+def _acc_ctx():
+    return getattr(_acc_tls, "current", None)
+
+
+def _acc_get(actx, key):
+    return actx.acc.get(key) if (actx is not None and actx.open) else None
+
+
+def _acc_put(actx, key, value):
+    """Remembers ALIASES (detach(): a new tensor object on the same storage) -- a second reference to the gradient tensor
+    itself would make autograd's AccumulateGrad copy it instead of adopting it as ``.grad`` (71 copies per iteration)."""
+    if actx is not None and actx.open:
+        actx.acc[key] = tuple(t.detach() for t in value) if isinstance(value, tuple) else value.detach()
+
+
 DEFER_MIN_WEIGHTS = 1 << 20
 DEFER_WGRAD = __import__("os").environ.get("VG_DEFER_WGRAD", "1") != "0"      # 0: deferred_wgrad() does nothing
 
@@ -116,6 +162,7 @@ class LinearFn(Function):
     def forward(ctx, x, w, bias, bias_grad=BIAS_GRAD_COMPUTE):
         ctx.save_for_backward(x, w)
         ctx.bias_grad = bias_grad
+        ctx.acc = _acc_ctx()
         dctx = getattr(_defer_tls, "current", None)
         ctx.defer = dctx if (dctx is not None and ctx.needs_input_grad[1] and w.numel() >= DEFER_MIN_WEIGHTS) else None
         if ctx.defer is not None:
@@ -145,7 +192,12 @@ class LinearFn(Function):
                     if len(pairs) > 1:
                         wg, wx = torch.cat([p[0] for p in pairs]), torch.cat([p[1] for p in pairs])
             if wg is not None:
-                gw = wg.t() @ wx
+                prev = _acc_get(ctx.acc, id(w))
+                if prev is None:
+                    gw = wg.t() @ wx
+                    _acc_put(ctx.acc, id(w), gw)
+                else:
+                    prev.addmm_(wg.t(), wx)                  # the layer's second use: added in the GEMM's epilogue
         return gx, gw, gb, None
 
 
@@ -164,6 +216,7 @@ class BNActFn(Function):
         else:
             y, mean, invstd = ops.bn_act_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, act)
         ctx.act = act
+        ctx.acc = _acc_ctx()
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
         return y
 
@@ -172,7 +225,12 @@ class BNActFn(Function):
     def backward(ctx, gy):
         x, gamma, beta, mean, invstd = ctx.saved_tensors
         need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
-        gx, dg, db = ops.bn_act_bwd(gy.contiguous(), x, gamma, beta, mean, invstd, ctx.act, need_p)
+        prev = _acc_get(ctx.acc, id(gamma)) if need_p else None
+        gx, dg, db = ops.bn_act_bwd(gy.contiguous(), x, gamma, beta, mean, invstd, ctx.act, need_p, accumulate_into=prev)
+        if prev is not None:
+            dg = db = None                                   # added into the first pass's tensors
+        elif need_p:
+            _acc_put(ctx.acc, id(gamma), (dg, db))
         return gx, dg, db, None, None, None, None, None, None
 
 
@@ -183,6 +241,7 @@ class ConvStatsFn(Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, transposed, bias_grad):
         ctx.stride, ctx.transposed, ctx.bias_grad = stride, transposed, bias_grad
+        ctx.acc = _acc_ctx()
         ctx.save_for_backward(x, w)
         conv = ops.convT5x5_fwd if transposed else ops.conv5x5_fwd
         y, stats = conv(x, w, bias, stride, want_stats=True)
@@ -205,7 +264,13 @@ class ConvStatsFn(Function):
                 raise RuntimeError("conv5x5 data gradient needs input sizes divisible by the stride")
             gx = ops.conv5x5_fwd(gy, w, None, s) if tr else ops.convT5x5_fwd(gy, w, None, s)
         if ctx.needs_input_grad[1]:
-            gw = ops.conv5x5_wgrad(gy, x, s) if tr else ops.conv5x5_wgrad(x, gy, s)
+            prev = _acc_get(ctx.acc, id(w))
+            kw = dict(out=prev, accumulate=True) if prev is not None else {}
+            gw = ops.conv5x5_wgrad(gy, x, s, **kw) if tr else ops.conv5x5_wgrad(x, gy, s, **kw)
+            if prev is not None:
+                gw = None                                    # added into the first pass's tensor
+            else:
+                _acc_put(ctx.acc, id(w), gw)
         if ctx.needs_input_grad[2]:
             gb = None if ctx.bias_grad == BIAS_GRAD_ZERO else ops.channel_sum(gy)
         return gx, gw, gb, None, None, None
@@ -233,6 +298,7 @@ class BNConvFn(Function):
         y, stats = conv(x, w, bias, stride, in_affine=(scale, shift, act), want_stats=True)
         stats = stats if stats is not None else x.new_empty(0)
         ctx.act, ctx.stride, ctx.transposed, ctx.bias_grad = act, stride, transposed, bias_grad
+        ctx.acc = _acc_ctx()
         ctx.save_for_backward(x, gamma, beta, mean, invstd, scale, shift, w)
         ctx.mark_non_differentiable(stats)
         ctx.set_materialize_grads(False)      # as ConvStatsFn
@@ -250,12 +316,23 @@ class BNConvFn(Function):
         gx = dg = db = gw = gb = None
         if need_bn:
             ga = ops.conv5x5_fwd(gy, w, None, s) if tr else ops.convT5x5_fwd(gy, w, None, s)    # grad w.r.t. act(BN(x))
-            gx, dg, db = ops.bn_act_bwd(ga, x, gamma, beta, mean, invstd, act,
-                                        ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+            need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+            prev = _acc_get(ctx.acc, id(gamma)) if need_p else None
+            gx, dg, db = ops.bn_act_bwd(ga, x, gamma, beta, mean, invstd, act, need_p, accumulate_into=prev)
+            if prev is not None:
+                dg = db = None                               # added into the first pass's tensors
+            elif need_p:
+                _acc_put(ctx.acc, id(gamma), (dg, db))
         if ctx.needs_input_grad[3]:
             aff = (scale, shift, act)
-            gw = ops.conv5x5_wgrad(gy, x, s, in_affine=aff, affine_on_gy=True) if tr \
-                else ops.conv5x5_wgrad(x, gy, s, in_affine=aff)
+            prev = _acc_get(ctx.acc, id(w))
+            kw = dict(out=prev, accumulate=True) if prev is not None else {}
+            gw = ops.conv5x5_wgrad(gy, x, s, in_affine=aff, affine_on_gy=True, **kw) if tr \
+                else ops.conv5x5_wgrad(x, gy, s, in_affine=aff, **kw)
+            if prev is not None:
+                gw = None
+            else:
+                _acc_put(ctx.acc, id(w), gw)
         if ctx.needs_input_grad[4]:
             gb = None if ctx.bias_grad == BIAS_GRAD_ZERO else ops.channel_sum(gy)
         return gx, dg, db, gw, gb, None, None, None, None, None, None, None, None, None
@@ -368,6 +445,7 @@ class DotSigmoidBCEFn(Function):
     def forward(ctx, feat, w, bias, target, divisor):
         p, loss, dlogit = ops.dot_sigmoid_bce_fwd(feat, w, bias, target, divisor, want_grad=True)
         ctx.save_for_backward(feat, w, dlogit)
+        ctx.acc = _acc_ctx()
         ctx.has_bias = bias is not None
         ctx.mark_non_differentiable(p)
         ctx.set_materialize_grads(False)
@@ -379,8 +457,14 @@ class DotSigmoidBCEFn(Function):
         if gloss is None:
             return None, None, None, None, None
         feat, w, dlogit = ctx.saved_tensors
-        gfeat, gw, gb = ops.dot_sigmoid_bce_bwd(dlogit, gloss.contiguous(), feat, w, ctx.needs_input_grad[0],
-                                                ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        prev = _acc_get(ctx.acc, id(w)) if (need_w and need_b) else None
+        gfeat, gw, gb = ops.dot_sigmoid_bce_bwd(dlogit, gloss.contiguous(), feat, w, ctx.needs_input_grad[0], need_w, need_b,
+                                                accumulate_into=prev)
+        if prev is not None:
+            gw = gb = None                                   # added into the first pass's tensors
+        elif need_w and need_b:
+            _acc_put(ctx.acc, id(w), (gw, gb))
         return gfeat, gw, gb, None, None
 
 

@@ -408,10 +408,14 @@ def convT5x5_fwd(x, w, bias, stride, in_affine=None, want_stats=False):
     return (y, None) if want_stats else y
 
 
-def conv5x5_wgrad(x, gy, stride, out=None, in_affine=None, affine_on_gy=False):
+def conv5x5_wgrad(x, gy, stride, out=None, in_affine=None, affine_on_gy=False, accumulate=False):
     """dw[Cout,Cin,5,5] for y = conv(x, w, stride); x (B,Cin,H,W), gy (B,Cout,OH,OW).  ``in_affine`` = (scale, shift,
     act): the operand x -- or gy when ``affine_on_gy`` (the weight gradient of a transposed convolution passes the
-    layer's input there) -- is read as act(v * scale[c] + shift[c]), on load where the kernel can."""
+    layer's input there) -- is read as act(v * scale[c] + shift[c]), on load where the kernel can.  ``accumulate``: the
+    result is added to what ``out`` holds (inside the kernel's final slab sum)."""
+    if accumulate and out is None:
+        raise RuntimeError("conv5x5_wgrad: accumulate needs the tensor to accumulate into (out=)")
+    acc = 1 if accumulate else 0
     lib = _lib.load()
     _req(x, "x"), _req(gy, "gy")
     B, Cin, H, W = x.shape
@@ -430,7 +434,7 @@ def conv5x5_wgrad(x, gy, stride, out=None, in_affine=None, affine_on_gy=False):
             with _timed(("conv_wgrad", B, Cin, H, W, Cout, stride)):
                 check(lib.vg_conv5x5_wgrad_bf16split(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout, stride,
                                                   _planes(), ws.data_ptr(), ws.numel(), _ptr(sc), _ptr(sh), int(act),
-                                                  1 if affine_on_gy else 0, _stream()), "vg_conv5x5_wgrad_bf16split")
+                                                  1 if affine_on_gy else 0, acc, _stream()), "vg_conv5x5_wgrad_bf16split")
             return dw
     if _planes() and THIN_SPLIT and Cin <= 3 and (in_affine is None or affine_on_gy):
         # <= 3 input channels: one read pass over gy (a producer's BatchNorm + activation applied to it on load: the weight
@@ -444,7 +448,7 @@ def conv5x5_wgrad(x, gy, stride, out=None, in_affine=None, affine_on_gy=False):
             with _timed(("conv_wgrad", B, Cin, H, W, Cout, stride)):
                 check(lib.vg_conv5x5_thin_wgrad_bf16split(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout,
                                                           stride, _planes(), ws.data_ptr(), ws.numel(), _ptr(sc), _ptr(sh),
-                                                          int(act), _stream()), "vg_conv5x5_thin_wgrad_bf16split")
+                                                          int(act), acc, _stream()), "vg_conv5x5_thin_wgrad_bf16split")
             return dw
     if in_affine is not None:      # the kernels below take the operand as a tensor
         if affine_on_gy:
@@ -457,14 +461,14 @@ def conv5x5_wgrad(x, gy, stride, out=None, in_affine=None, affine_on_gy=False):
             ws = workspace(need, x.device)
             with _timed(("conv_wgrad", B, Cin, H, W, Cout, stride)):
                 check(lib.vg_conv5x5_thin_wgrad_bf16split(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout,
-                                                          stride, _planes(), ws.data_ptr(), ws.numel(), None, None, 0,
+                                                          stride, _planes(), ws.data_ptr(), ws.numel(), None, None, 0, acc,
                                                           _stream()), "vg_conv5x5_thin_wgrad_bf16split")
             return dw
     need = lib.vg_conv5x5_wgrad_workspace_bytes(B, Cin, H, W, Cout, stride)
     ws = workspace(need, x.device)
     with _timed(("conv_wgrad", B, Cin, H, W, Cout, stride)):
         check(lib.vg_conv5x5_wgrad(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout, stride,
-                                   ws.data_ptr(), ws.numel(), _stream()), "vg_conv5x5_wgrad")
+                                   ws.data_ptr(), ws.numel(), acc, _stream()), "vg_conv5x5_wgrad")
     return dw
 
 
@@ -540,18 +544,23 @@ def affine_act(x, scale, shift, act):
     return y
 
 
-def bn_act_bwd(gy, x, gamma, beta, mean, invstd, act, need_param_grads=True):
+def bn_act_bwd(gy, x, gamma, beta, mean, invstd, act, need_param_grads=True, accumulate_into=None):
+    """``accumulate_into`` = (dgamma, dbeta) tensors the parameter gradients are ADDED to (the layer's second use before
+    one backward); they are then returned as they are."""
     lib = _lib.load()
     _req(gy, "gy"), _req(x, "x")
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
     gx = torch.empty_like(x)
-    dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if need_param_grads else None
-    dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if need_param_grads else None
+    if accumulate_into is not None:
+        dgamma, dbeta = accumulate_into
+    else:
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if need_param_grads else None
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if need_param_grads else None
     ws = workspace(lib.vg_bn_workspace_bytes(C), x.device)
     check(lib.vg_bn_act_bwd(gy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
                             invstd.data_ptr(), gx.data_ptr(), _ptr(dgamma), _ptr(dbeta), B, C, HW, act,
-                            ws.data_ptr(), ws.numel(), _stream()), "vg_bn_act_bwd")
+                            1 if accumulate_into is not None else 0, ws.data_ptr(), ws.numel(), _stream()), "vg_bn_act_bwd")
     return gx, dgamma, dbeta
 
 
@@ -668,14 +677,19 @@ def dot_sigmoid_bce_fwd(feat, w, bias, target, divisor=None, want_grad=True):
     return p, loss, dlogit
 
 
-def dot_sigmoid_bce_bwd(dlogit, gloss, feat, w, need_feat=True, need_w=True, need_b=True):
+def dot_sigmoid_bce_bwd(dlogit, gloss, feat, w, need_feat=True, need_w=True, need_b=True, accumulate_into=None):
+    """``accumulate_into`` = (gw, gb) tensors the parameter gradients are added to (see bn_act_bwd)."""
     lib = _lib.load()
     B, K = feat.shape
     gfeat = torch.empty_like(feat) if need_feat else None
-    gw = torch.empty(w.shape, dtype=torch.float32, device=feat.device) if need_w else None
-    gb = torch.empty(1, dtype=torch.float32, device=feat.device) if need_b else None
+    if accumulate_into is not None:
+        gw, gb = accumulate_into
+    else:
+        gw = torch.empty(w.shape, dtype=torch.float32, device=feat.device) if need_w else None
+        gb = torch.empty(1, dtype=torch.float32, device=feat.device) if need_b else None
     check(lib.vg_dot_sigmoid_bce_bwd(dlogit.data_ptr(), _ptr(gloss), feat.data_ptr(), w.data_ptr(), _ptr(gfeat), _ptr(gw),
-                                     _ptr(gb), B, K, _stream()), "vg_dot_sigmoid_bce_bwd")
+                                     _ptr(gb), B, K, 1 if accumulate_into is not None else 0, _stream()),
+          "vg_dot_sigmoid_bce_bwd")
     return gfeat, gw, gb
 
 

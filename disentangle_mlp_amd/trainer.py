@@ -527,6 +527,11 @@ class BetaVAEGANTrainer(_GraphedSteps):
             {"d": netD, "eg": netEG})
 
     def _step_body(self, data, noise, eps2, eps3, real_label, fake_label, global_batch, grad_hook, prepack):
+        # layers applied twice before one backward add their second parameter gradient inside its own kernel
+        with F.accumulate_param_grads() as acc:
+            return self._phases(data, noise, eps2, eps3, real_label, fake_label, global_batch, grad_hook, prepack, acc)
+
+    def _phases(self, data, noise, eps2, eps3, real_label, fake_label, global_batch, grad_hook, prepack, acc):
         netEG, netD = self.netEG, self.netD
         B = data.size(0)
         prepack()
@@ -548,6 +553,7 @@ class BetaVAEGANTrainer(_GraphedSteps):
         self.optimizerD.step()
         ops.invalidate_packed_filters(self._d_params)
         prepack("d")
+        acc.reset()
         out["errD_real"], out["errD_fake"] = err_real.detach(), err_fake.detach()
         out["D_x_sum"] = p_real.detach().sum()
 
@@ -569,6 +575,7 @@ class BetaVAEGANTrainer(_GraphedSteps):
         self.optimizerEG.step()
         ops.invalidate_packed_filters(self._eg_params)
         prepack("eg")
+        acc.reset()
         out.update(errG_fake=err_g_fake.detach(), errG_recon=err_g_rec.detach(), sim=sim.detach(),
                    mse_dec=mse2.detach())
 
@@ -861,6 +868,10 @@ class GANTrainer(_GraphedSteps):
             {"d": self.netD, "g": self.netG})
 
     def _step_body(self, data, noise, real_label, fake_label, global_batch, grad_hook, prepack):
+        with F.accumulate_param_grads() as acc:              # D runs twice before its backward (as BetaVAEGANTrainer)
+            return self._phases(data, noise, real_label, fake_label, global_batch, grad_hook, prepack, acc)
+
+    def _phases(self, data, noise, real_label, fake_label, global_batch, grad_hook, prepack, acc):
         B = data.size(0)
         gb = global_batch if global_batch is not None else B * self.world
         prepack()
@@ -876,6 +887,7 @@ class GANTrainer(_GraphedSteps):
         self.optimizerD.step()
         ops.invalidate_packed_filters([p for p in self.netD.parameters() if p.dim() == 4])
         prepack("d")
+        acc.reset()
         self._zero(self.netG, self.flat_g)
         for p in self.netD.parameters():
             p.requires_grad_(False)

@@ -176,7 +176,8 @@ int vg_conv5x5_thin_wgrad_bf16split(const float* x, const float* gy, float* dw, 
                                     /* gy read as act(gy * gy_scale[c] + gy_shift[c]) (NULL, NULL, 0: plain): the weight
                                      * gradient of ConvTranspose2d(32, 3) passes the layer's input here, the train-mode
                                      * BatchNorm + ReLU of its producer (model.py:505) is applied on load */
-                                    const float* gy_scale, const float* gy_shift, int gy_act, void* stream);
+                                    const float* gy_scale, const float* gy_shift, int gy_act,
+                                    int accumulate /* dw += (see vg_conv5x5_wgrad) */, void* stream);
 /* vg_conv5x5_wgrad in the same arithmetic.  The reduction runs over images in groups of 16: gy is re-laid
  * batch-innermost inside the call (B zero-padded to a multiple of 16), x is staged straight from NCHW; needs
  * OW % 8 == 0 -- the workspace query returns 0 for shapes it does not take (use vg_conv5x5_wgrad).
@@ -185,7 +186,7 @@ size_t vg_conv5x5_wgrad_bf16split_workspace_bytes(int B, int Cin, int H, int W, 
 int vg_conv5x5_wgrad_bf16split(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W,
                             int Cout, int stride, int planes, void* workspace, size_t workspace_bytes,
                             const float* in_scale, const float* in_shift, int in_act, int affine_on_gy,
-                            void* stream);
+                            int accumulate /* dw += (see vg_conv5x5_wgrad) */, void* stream);
 /* in_scale / in_shift / in_act: one operand is read as act(v * scale[c] + shift[c]) (vg_conv_fusion semantics) --
  * x (Cin coefficients) when affine_on_gy == 0, gy (Cout coefficients; the weight gradient of a transposed
  * convolution passes the layer's input there) otherwise.  NULL, NULL, 0, 0: both operands as they are. */
@@ -197,7 +198,12 @@ int vg_conv5x5_wgrad_bf16split(const float* x, const float* gy, float* dw, int B
  * split-K partial slabs in `workspace` are summed in a fixed order. */
 size_t vg_conv5x5_wgrad_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride);
 int vg_conv5x5_wgrad(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W,
-                     int Cout, int stride, void* workspace, size_t workspace_bytes, void* stream);
+                     int Cout, int stride, void* workspace, size_t workspace_bytes,
+                     /* accumulate != 0: the result is ADDED to what dw holds (in the final fixed-order slab sum) -- a layer
+                      * applied twice before one backward (D on the real and the generated batch, the decoder on the prior
+                      * sample and the reconstruction: new_betavaegan.py:99-121, 144-163) gets its second weight gradient
+                      * without the separate addition autograd would launch; fp addition is commutative: same bits */
+                     int accumulate, void* stream);
 
 /* out[c] = sum_{b,hw} g[b,c,hw]   (bias gradient of the convolutions).
  * workspace >= vg_bn_workspace_bytes(C). */
@@ -223,6 +229,7 @@ int vg_bn_act_bwd(const float* gy, const float* x, const float* gamma, const flo
                   const float* save_mean, const float* save_invstd,
                   float* gx, float* dgamma, float* dbeta,
                   int B, int C, int HW, int act,
+                  int accumulate_param_grads /* dgamma, dbeta += (a layer used twice before one backward) */,
                   void* workspace, size_t workspace_bytes, void* stream);
 /* Fused-BatchNorm helpers.  vg_bn_finalize_stats turns a convolution's statistics slots
  * ([nslots][C][2] floats: vg_conv_fusion.stats) into the coefficients of the train-mode BatchNorm that follows it
@@ -301,7 +308,7 @@ int vg_dot_sigmoid_bce_fwd(const float* feat, const float* w, const float* bias,
                            float* p, float* loss, float* dlogit, int B, int K, float divisor,
                            void* workspace, size_t workspace_bytes, void* stream);
 int vg_dot_sigmoid_bce_bwd(const float* dlogit, const float* gloss, const float* feat, const float* w, float* gfeat,
-                           float* gw, float* gb, int B, int K, void* stream);
+                           float* gw, float* gb, int B, int K, int accumulate_param_grads /* gw, gb += */, void* stream);
 
 /* ---- Adam (experiments/new_betavaegan.py:49-50: optim.Adam defaults, stepped 3x per iteration)
  * For each tensor: m += (1-beta1)(g-m); v = beta2 v + (1-beta2) g^2;

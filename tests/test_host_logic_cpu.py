@@ -249,3 +249,32 @@ def test_tuned_gemm_table_is_well_formed_and_inert_without_a_gpu():
     if not torch.cuda.is_available():
         assert tuned_gemms.enable() is False
 
+
+def test_accumulate_param_grads_adds_inside_the_second_pass(monkeypatch):
+    """functional.accumulate_param_grads(): a layer applied twice before one backward hands autograd ONE gradient tensor;
+    the second pass adds into it (here the Linear Function: addmm_) -- same gradients as autograd's own sum; reset()
+    separates two backwards; outside a context nothing changes."""
+    from disentangle_mlp_amd import functional as HF
+    torch.manual_seed(1)
+    w, b = torch.randn(6, 5, requires_grad=True), torch.randn(6, requires_grad=True)
+    x1, x2 = torch.randn(4, 5), torch.randn(3, 5)
+
+    def loss():
+        return HF.linear(x1, w, b).pow(2).sum() + HF.linear(x2, w, b).sin().sum()
+    ref = torch.nn.functional.linear(x1, w, b).pow(2).sum() + torch.nn.functional.linear(x2, w, b).sin().sum()
+    gw, gb = torch.autograd.grad(ref, (w, b))
+    calls = []
+    orig = torch.Tensor.addmm_
+    monkeypatch.setattr(torch.Tensor, "addmm_", lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1])
+    with HF.accumulate_param_grads() as acc:
+        loss().backward()
+        assert len(calls) == 1 and len(acc.acc) == 1           # the second pass added in place
+        assert torch.allclose(w.grad, gw, rtol=1e-6, atol=1e-6) and torch.allclose(b.grad, gb, rtol=1e-6, atol=1e-6)
+        acc.reset()
+        w.grad = b.grad = None
+        loss().backward()                                       # a new backward starts from nothing
+        assert torch.allclose(w.grad, gw, rtol=1e-6, atol=1e-6) and len(calls) == 2
+    w.grad = b.grad = None
+    loss().backward()                                           # no context: autograd's own accumulation
+    assert torch.allclose(w.grad, gw, rtol=1e-6, atol=1e-6) and len(calls) == 2
+
