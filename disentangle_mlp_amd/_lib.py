@@ -36,7 +36,6 @@ SIGNATURES = {
     "vg_convT5x5_fwd_bf16split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P]),
     "vg_conv5x5_fwd_bf16split_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "vg_conv5x5_bf16split_fusable": (_I, [_I, _I, _I, _I]),
-    "vg_conv5x5_bf16split_in_affine_ok": (_I, [_I, _I, _I, _I]),
     "vg_conv5x5_fwd_bf16split_stats_floats": (_Z, [_I, _I, _I, _I, _I, _I]),
     "vg_convT5x5_fwd_bf16split_stats_floats": (_Z, [_I, _I, _I, _I, _I, _I]),
     "vg_convT5x5_s1_thin_bf16split_ok": (_I, [_I, _I, _I, _I]),

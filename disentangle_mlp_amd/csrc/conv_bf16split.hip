@@ -78,12 +78,6 @@ struct XArgs {
   int ntiles_n, tiles_w, tiles_hw, blocks_per_cls;
   int ksplit, cps;       // forward only: grid-level split of the channel chunks (deep-K, small-grid layers)
   size_t ysplit;         // elements per partial output slab (then y points at the slabs)
-  // the input read as act(x * in_scale[c] + in_shift[c]) -- the producing layer's train-mode BatchNorm + activation,
-  // applied while the patch is staged (zero padding pads the ACTIVATED tensor); NULL: plain.  (Statistics of the
-  // output are the ring kernel's business: vg_conv5x5_bf16split_fusable.)
-  const float* in_scale;
-  const float* in_shift;
-  float in_slope;
 };
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
@@ -138,7 +132,7 @@ __device__ __forceinline__ void bf16split_body(const XArgs& A, f32x4* lds, int b
 
   // ---- staging map: unit e = (k-block, image, row, column); addresses clamped, validity masked
   int pofs[NQ], pdst[NQ];
-  unsigned pvalid = 0, pkb = 0;      // per staged unit: inside the image; k-block (channels 8-15 of the chunk)
+  unsigned pvalid = 0;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int e = tid + q * XNT;
@@ -153,15 +147,11 @@ __device__ __forceinline__ void bf16split_body(const XArgs& A, f32x4* lds, int b
     pofs[q] = (nbc * Cin + kbs * 8) * HW + ihc * XW + iwc;
     pdst[q] = (e < C::NUNIT) ? kbs * IMGU + (nb * PH + r) * ROWU + (C::SPLIT ? (col & 1) * COLS + (col >> 1) : col) : -1;
     pvalid |= ok ? (1u << q) : 0u;
-    pkb |= kbs ? (1u << q) : 0u;
   }
   static_assert(NQ <= 32, "validity mask");
 
   float preg[NQ][8];
-  int staged_c0 = 0;
-  const bool aff = A.in_scale != nullptr;            // wave-uniform
   auto load_chunk = [&](int c0) {
-    staged_c0 = c0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -171,14 +161,6 @@ __device__ __forceinline__ void bf16split_body(const XArgs& A, f32x4* lds, int b
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const bool ok = (pvalid >> q) & 1u;
-      if (aff) {                                     // the producer's BatchNorm + activation, on load
-        const int cb = staged_c0 + (((pkb >> q) & 1u) ? 8 : 0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float v = fmaf(preg[q][j], A.in_scale[cb + j], A.in_shift[cb + j]);
-          preg[q][j] = fmaxf(v, 0.f) + A.in_slope * fminf(v, 0.f);
-        }
-      }
       bf16x8 pl[NP];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -348,9 +330,6 @@ __global__ __launch_bounds__(XNT, 2) void conv5x5_bf16split_kernel(XArgs A) {
 struct XSplit {
   int k;          // 1: no split
   float* slabs;   // k partial outputs
-  const float* in_scale = nullptr;      // input BatchNorm + activation on load (XArgs)
-  const float* in_shift = nullptr;
-  int in_act = 0;
 };
 
 template <class C>
@@ -358,8 +337,6 @@ int launch_x(const float* x, const bf16x8* w, const float* bias, float* y, int B
              XSplit xs, hipStream_t st) {
   XArgs A;
   A.x = x; A.w = w; A.bias = bias; A.y = y;
-  A.in_scale = xs.in_scale; A.in_shift = xs.in_shift;
-  A.in_slope = (!xs.in_scale || xs.in_act == VG_ACT_NONE) ? 1.f : (xs.in_act == VG_ACT_RELU ? 0.f : 0.2f);
   A.B = B; A.Cin = Cin; A.XH = XH; A.XW = XW; A.Cout = Cout; A.CoutP = (Cout + 127) & ~127;
   int tsh, tsw;
   if (C::MODE == X_FWD) {
@@ -648,16 +625,7 @@ extern "C" size_t vg_conv5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H
   return (size_t)k * B * Cout * ((H - 1) / stride + 1) * ((W - 1) / stride + 1) * sizeof(float);
 }
 
-// kernels of this file: input BatchNorm + activation on load yes, output statistics no
-static bool fuse_affine_only(const vg_conv_fusion* f) {
-  return !f || (!f->stats && (f->in_scale == nullptr) == (f->in_shift == nullptr) && f->in_act >= VG_ACT_NONE &&
-                f->in_act <= VG_ACT_LRELU);
-}
-
-extern "C" int vg_conv5x5_bf16split_in_affine_ok(int transposed, int Cin, int Cout, int stride) {
-  (void)transposed; (void)Cout;
-  return (Cin > 0 && Cin % 16 == 0 && (stride == 1 || stride == 2)) ? 1 : 0;      // every split-bf16 convolution kernel
-}
+static bool fuse_empty(const vg_conv_fusion* f) { return !f || (!f->in_scale && !f->in_shift && !f->stats); }
 
 extern "C" int vg_conv5x5_bf16split_fusable(int transposed, int Cin, int Cout, int stride) {
   if (Cin <= 0 || Cin % 16 || Cout <= 0) return 0;
@@ -683,13 +651,12 @@ extern "C" int vg_conv5x5_fwd_bf16split(const float* x, const void* packed, cons
     return vg_internal_ring_conv(0, x, packed, bias, y, B, Cin, H, W, Cout, planes, workspace, workspace_bytes,
                                  fuse ? fuse->in_scale : nullptr, fuse ? fuse->in_shift : nullptr, fuse ? fuse->in_act : 0,
                                  fuse ? fuse->stats : nullptr, fuse ? fuse->stats_floats : 0, st);
-  if (!fuse_affine_only(fuse)) return VG_ERR_BAD_ARG;  // statistics: vg_conv5x5_bf16split_fusable says which layers emit them
+  if (!fuse_empty(fuse)) return VG_ERR_BAD_ARG;        // vg_conv5x5_bf16split_fusable says which layers take it
   const bf16x8* w = (const bf16x8*)packed;
   const int k = fwd_ksplit(B, Cin, H, W, Cout, stride);
   if (k > 1 && (!workspace || workspace_bytes < vg_conv5x5_fwd_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride)))
     return VG_ERR_WORKSPACE;
-  XSplit xs = {k, (float*)workspace};
-  if (fuse) { xs.in_scale = fuse->in_scale; xs.in_shift = fuse->in_shift; xs.in_act = fuse->in_act; }
+  const XSplit xs = {k, (float*)workspace};
   if (planes == 2) return dispatch_x<X_FWD, 1, 2>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
   return dispatch_x<X_FWD, 1, 3>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
 }
@@ -708,14 +675,12 @@ extern "C" int vg_convT5x5_fwd_bf16split(const float* x, const void* packed, con
     return vg_internal_ring_conv(1, x, packed, bias, y, B, Cin, H, W, Cout, planes, workspace, workspace_bytes,
                                  fuse ? fuse->in_scale : nullptr, fuse ? fuse->in_shift : nullptr, fuse ? fuse->in_act : 0,
                                  fuse ? fuse->stats : nullptr, fuse ? fuse->stats_floats : 0, st);
-  if (!fuse_affine_only(fuse)) return VG_ERR_BAD_ARG;
+  if (!fuse_empty(fuse)) return VG_ERR_BAD_ARG;
   const bf16x8* w = (const bf16x8*)packed;
-  XSplit xs = {1, nullptr};
-  if (fuse) { xs.in_scale = fuse->in_scale; xs.in_shift = fuse->in_shift; xs.in_act = fuse->in_act; }
   if (planes == 2) {
-    if (stride == 2) return dispatch_x<X_TR, 2, 2>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
-    return dispatch_x<X_TR, 1, 2>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
+    if (stride == 2) return dispatch_x<X_TR, 2, 2>(x, w, bias, y, B, Cin, H, W, Cout, XSplit{1, nullptr}, st);
+    return dispatch_x<X_TR, 1, 2>(x, w, bias, y, B, Cin, H, W, Cout, XSplit{1, nullptr}, st);
   }
-  if (stride == 2) return dispatch_x<X_TR, 2, 3>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
-  return dispatch_x<X_TR, 1, 3>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
+  if (stride == 2) return dispatch_x<X_TR, 2, 3>(x, w, bias, y, B, Cin, H, W, Cout, XSplit{1, nullptr}, st);
+  return dispatch_x<X_TR, 1, 3>(x, w, bias, y, B, Cin, H, W, Cout, XSplit{1, nullptr}, st);
 }

@@ -306,7 +306,7 @@ def conv5x5_fwd(x, w, bias, stride, in_affine=None, want_stats=False):
     stats = None
     if _planes() and Cin % 16 == 0:
         fus = conv_fusable(False, Cin, Cout, stride)
-        if in_affine is not None and not lib.vg_conv5x5_bf16split_in_affine_ok(0, Cin, Cout, stride):
+        if in_affine is not None and not fus:
             x, in_affine = _materialize(x, in_affine), None
         if want_stats and fus:
             n = lib.vg_conv5x5_fwd_bf16split_stats_floats(B, Cin, H, W, Cout, stride)
@@ -370,7 +370,7 @@ def convT5x5_fwd(x, w, bias, stride, in_affine=None, want_stats=False):
     stats = None
     if _planes() and Cin % 16 == 0 and not thin:
         fus = conv_fusable(True, Cin, Cout, stride)
-        if in_affine is not None and not lib.vg_conv5x5_bf16split_in_affine_ok(1, Cin, Cout, stride):
+        if in_affine is not None and not fus:
             x, in_affine = _materialize(x, in_affine), None
         if want_stats and fus:
             n = lib.vg_convT5x5_fwd_bf16split_stats_floats(B, Cin, H, W, Cout, stride)

@@ -121,9 +121,6 @@ typedef struct vg_conv_fusion {
   size_t stats_floats;
 } vg_conv_fusion;
 int vg_conv5x5_bf16split_fusable(int transposed, int Cin, int Cout, int stride);
-/* 1 when the layer's kernel applies in_scale / in_shift / in_act on load (every split-bf16 convolution: Cin % 16 == 0);
- * `_fusable` above additionally says that it can emit `stats` (the stride-2 ring kernels). */
-int vg_conv5x5_bf16split_in_affine_ok(int transposed, int Cin, int Cout, int stride);
 size_t vg_conv5x5_fwd_bf16split_stats_floats(int B, int Cin, int H, int W, int Cout, int stride);
 size_t vg_convT5x5_fwd_bf16split_stats_floats(int B, int Cin, int H, int W, int Cout, int stride);
 size_t vg_conv5x5_packed_bf16split_bytes(int Cout, int Cin, int planes);

@@ -762,37 +762,6 @@ def test_stats_epilogue_at_the_benchmarked_sizes(H, B, transposed, Cin, Cout, Hs
                                                                 what=f"B={B} fused launch")
 
 
-@pytest.mark.parametrize("transposed,stride,B,Cin,Cout,Hs,Ws,act", [
-    (True, 2, 128, 128, 32, 32, 32, "relu"),          # deconv3 at the benchmark's size (its input is act2(BN(deconv2)))
-    (True, 2, 3, 32, 48, 10, 14, "lrelu"), (True, 1, 2, 16, 40, 12, 20, "relu"), (False, 1, 3, 32, 70, 9, 16, "lrelu")])
-def test_input_affine_on_load_in_the_small_tile_kernels(H, transposed, stride, B, Cin, Cout, Hs, Ws, act):
-    """conv_bf16split.hip (stride 1, and transposed outputs of <= 64 channels: deconv3) applies the producer's
-    BatchNorm + activation while it stages its patch, like the ring kernels -- round 2 materialised the tensor for them.
-    fp64 oracle of the materialised computation (at B = 128 on corner crops)."""
-    code = {"relu": 1, "lrelu": 2}[act]
-    gen = torch.Generator(device="cuda").manual_seed(74)
-    x = torch.randn(B, Cin, Hs, Ws, device="cuda", generator=gen)
-    scale = 0.5 + torch.rand(Cin, device="cuda", generator=gen)
-    shift = torch.randn(Cin, device="cuda", generator=gen)
-    w = 0.05 * torch.randn(*((Cin, Cout, 5, 5) if transposed else (Cout, Cin, 5, 5)), device="cuda", generator=gen)
-    bias = torch.randn(Cout, device="cuda", generator=gen)
-    conv = H.convT5x5_fwd if transposed else H.conv5x5_fwd
-    lib = __import__("disentangle_mlp_amd._lib", fromlist=["load"]).load()
-    assert lib.vg_conv5x5_bf16split_in_affine_ok(int(transposed), Cin, Cout, stride) == 1
-    assert not H.conv_fusable(transposed, Cin, Cout, stride)          # no statistics from these kernels
-    y, stats = conv(x, w, bias, stride, in_affine=(scale, shift, code), want_stats=True)
-    assert stats is None
-
-    def prep(t):
-        a = t * scale.double().cpu().view(1, -1, 1, 1) + shift.double().cpu().view(1, -1, 1, 1)
-        return a.clamp(min=0) if act == "relu" else torch.where(a > 0, a, 0.2 * a)
-    if B > 8:
-        (_convT_corner_crops if transposed else _conv_corner_crops)(y, x, w, bias, stride, prep=prep, tol=CONV_TOL, what="B=128")
-    else:
-        ref = (O.convT5x5 if transposed else O.conv5x5)(prep(x.double().cpu()), w.cpu(), bias.cpu(), stride)
-        assert_close(y, ref, CONV_TOL, "input affine on load")
-
-
 def test_stats_epilogue_with_a_large_channel_mean(H):
     """The epilogue's statistics are E[y^2] - mean^2 from fp32 per-wavefront slot sums (64-128 values each) combined in
     fp64: the slot sums' rounding errors are independent, so over the 512-2048 slots of a B = 128 launch they average
