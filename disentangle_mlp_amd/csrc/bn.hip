@@ -216,6 +216,79 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
   }
 }
 
+// Backward in ONE pass for channels that fit a workgroup's registers (B * HW <= ONE_NT * 4 * NV elements: the 16 x 16 and
+// 8 x 8 layers at B = 128): a workgroup of 16 wavefronts owns a channel, holds its (x, gy) in registers (2 * NV float4 per
+// lane), sums g_pre and g_pre * xhat in fp64 in a fixed order, and writes gx from the registers -- two reads and one write
+// per element where the two-pass form above reads (x, gy) twice.  Same formulas as bn_partial_kernel<1> +
+// bn_apply_kernel<true>; only the order of the fp64 sums differs.
+constexpr int ONE_NT = 1024;
+
+template <int NV>
+__global__ __launch_bounds__(ONE_NT) void bn_bwd_onepass_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, float* __restrict__ gx,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                int B, int C, int HW, int act) {
+  __shared__ double red[ONE_NT / 64];
+  __shared__ float s_c[2];
+  const bool accp = (act & 0x100) != 0;
+  act &= 0xff;
+  const int c = blockIdx.x;
+  const int total = B * HW;
+  const int hw_shift = (HW & (HW - 1)) == 0 ? __builtin_ctz(HW) : -1;
+  const float mu = mean[c], is = invstd[c], sc = gamma[c] * is, sh = beta[c] - mu * sc;
+  float4 xv[NV], gv[NV];
+  size_t off[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int v = (j * ONE_NT + (int)threadIdx.x) * 4;
+    const int vc = min(v, total - 4);                       // clamped, unconditional; masked below
+    const int b = hw_shift >= 0 ? (vc >> hw_shift) : vc / HW, hw = vc - b * HW;
+    off[j] = ((size_t)b * C + c) * HW + hw;
+    xv[j] = *reinterpret_cast<const float4*>(x + off[j]);
+    gv[j] = *reinterpret_cast<const float4*>(gy + off[j]);
+  }
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const bool ok = (j * ONE_NT + (int)threadIdx.x) * 4 < total;
+    float* xp = reinterpret_cast<float*>(&xv[j]);
+    float* gp = reinterpret_cast<float*>(&gv[j]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float g = ok ? act_grad(fmaf(xp[e], sc, sh), gp[e], act) : 0.f;
+      gp[e] = g;                                            // g_pre replaces gy
+      s1 += g;
+      s2 += (double)(g * ((xp[e] - mu) * is));
+    }
+  }
+  const double t1 = block_sum<ONE_NT>(s1, red);
+  const double t2 = block_sum<ONE_NT>(s2, red);
+  if (threadIdx.x == 0) {
+    const double count = (double)total;
+    s_c[0] = (float)(t1 / count);
+    s_c[1] = (float)(t2 / count);
+    if (dbeta) dbeta[c] = (float)t1 + (accp ? dbeta[c] : 0.f);
+    if (dgamma) dgamma[c] = (float)t2 + (accp ? dgamma[c] : 0.f);
+  }
+  __syncthreads();
+  const float c1 = s_c[0], c2 = s_c[1];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    if ((j * ONE_NT + (int)threadIdx.x) * 4 >= total) continue;
+    const float* xp = reinterpret_cast<const float*>(&xv[j]);
+    const float* gp = reinterpret_cast<const float*>(&gv[j]);
+    float4 o;
+    o.x = sc * (gp[0] - c1 - ((xp[0] - mu) * is) * c2);
+    o.y = sc * (gp[1] - c1 - ((xp[1] - mu) * is) * c2);
+    o.z = sc * (gp[2] - c1 - ((xp[2] - mu) * is) * c2);
+    o.w = sc * (gp[3] - c1 - ((xp[3] - mu) * is) * c2);
+    *reinterpret_cast<float4*>(gx + off[j]) = o;
+  }
+}
+
 // BatchNorm1d: x [B][C].  A workgroup owns 32 consecutive channels (128-byte coalesced rows);
 // its 8 row-slices (threads 32*s .. 32*s+31) each sum every 8th batch row in fp64 and combine
 // through LDS in a fixed order; the normalise / gradient pass re-reads the rows from L2.
@@ -654,6 +727,23 @@ extern "C" int vg_bn_act_bwd(const float* gy, const float* x, const float* gamma
   if (HW == 1) {
     hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(cdiv(C, B1_CH)), dim3(NT), 0, st, gy, x, gamma, beta, save_mean,
                        save_invstd, gx, dgamma, dbeta, B, C, act_apply);
+    VG_CHECK_LAUNCH();
+    return 0;
+  }
+  // one pass when a channel fits a workgroup's registers and there are channels enough to fill the chip's memory system
+  const long per_channel = (long)B * HW;
+#ifdef VG_BN_TWO_PASS                  // timing experiments only (same-box A/B of the one-pass form)
+  constexpr bool one_pass = false;
+#else
+  constexpr bool one_pass = true;
+#endif
+  if (one_pass && (HW & 3) == 0 && per_channel >= 4 && per_channel <= (long)ONE_NT * 4 * 8 && C >= 128) {
+    if (per_channel <= (long)ONE_NT * 4 * 2)
+      hipLaunchKernelGGL(bn_bwd_onepass_kernel<2>, dim3(C), dim3(ONE_NT), 0, st, x, gy, gamma, beta, save_mean, save_invstd,
+                         gx, dgamma, dbeta, B, C, HW, act_apply);
+    else
+      hipLaunchKernelGGL(bn_bwd_onepass_kernel<8>, dim3(C), dim3(ONE_NT), 0, st, x, gy, gamma, beta, save_mean, save_invstd,
+                         gx, dgamma, dbeta, B, C, HW, act_apply);
     VG_CHECK_LAUNCH();
     return 0;
   }

@@ -214,7 +214,11 @@ def test_conv_ragged(H, conv_arith, B, Cin, Cout, Hs, Ws, stride):
 
 
 @pytest.mark.parametrize("shape,act", [((8, 32, 64, 64), "lrelu"), ((8, 256, 8, 8), "relu"), ((5, 7, 3, 5), "none"),
-                                       ((16, 2048), "relu"), ((128, 16384), "relu"), ((16, 3, 1, 1), "lrelu")])
+                                       ((16, 2048), "relu"), ((128, 16384), "relu"), ((16, 3, 1, 1), "lrelu"),
+                                       # backward in one pass (a channel in one workgroup's registers): full and ragged
+                                       # loads of both instantiations, a plane that is not a power of two
+                                       ((128, 256, 16, 16), "lrelu"), ((96, 128, 16, 16), "relu"), ((128, 256, 8, 8), "relu"),
+                                       ((33, 256, 16, 16), "lrelu"), ((3, 128, 10, 10), "none"), ((1, 128, 2, 2), "relu")])
 def test_bn_shapes(H, shape, act):
     x = _rand(*shape, seed=20) * 2 + 0.5
     C = shape[1]
@@ -231,6 +235,11 @@ def test_bn_shapes(H, shape, act):
     assert_close(gx, ref["gx"], 2e-5, "gx")
     assert_close(gw, ref["gw"], 2e-5, "dgamma")
     assert_close(gb, ref["gb"], 2e-5, "dbeta")
+    # the layer's second use before one backward: parameter gradients added to what is there, gx the same bits
+    acc = (gw.clone(), gb.clone())
+    gx2, gw2, gb2 = H.bn_act_bwd(gy.cuda(), x.cuda(), gamma.cuda(), beta.cuda(), mean, invstd, code, accumulate_into=acc)
+    assert torch.equal(gx2, gx) and gw2 is acc[0] and gb2 is acc[1]
+    assert torch.equal(gw2, gw + gw) and torch.equal(gb2, gb + gb)
 
 
 def test_losses_full_size(H):
