@@ -274,7 +274,7 @@ GRAPH_WARM_STEPS = 2      # eager iterations of a shape before it is captured (w
 
 
 class _CapturedIteration:
-    """One training iteration captured in a HIP graph (torch.cuda.CUDAGraph) and replayed: ~570 kernel launches become
+    """One training iteration captured in a HIP graph (torch.cuda.CUDAGraph) and replayed: ~390 kernel launches become
     one graph launch, so the host no longer paces the GPU.
 
     What the graph freezes and how it stays correct from replay to replay:
@@ -422,7 +422,7 @@ class BetaVAEGANTrainer(_GraphedSteps):
 
     ``graph`` (default: on for a single-process CUDA trainer, VG_GRAPH=0 turns it off): from the third iteration of a
     batch shape on, `step` replays a HIP graph of the whole iteration (`_CapturedIteration`) instead of launching its
-    ~570 kernels one by one.  Iterations that need the host in the loop stay eager: a ``grad_hook``, data parallelism
+    ~390 kernels one by one.  Iterations that need the host in the loop stay eager: a ``grad_hook``, data parallelism
     (the gradient exchange runs from autograd hooks), launch timing (bench.py's instrumented step)."""
 
     def __init__(self, device="cuda", seed=999, beta=25.0, lr=1e-3, opt: Optional[ModelOpt] = None,
