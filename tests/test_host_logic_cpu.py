@@ -148,10 +148,10 @@ def _bucket_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_bucketed_overlapped_allreduce_two_ranks():
-    """The bucketed, hook-driven gradient exchange (what runs over RCCL on the GPUs) with 2 gloo
-    ranks equals the sum of the two ranks' gradients; buckets fire during backward."""
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_bucketed_overlapped_allreduce_two_ranks(world):
+    """The bucketed, hook-driven gradient exchange (what runs over RCCL on the GPUs) with 2 and with 4 gloo
+    ranks equals the sum of the ranks' gradients; buckets fire during backward."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
