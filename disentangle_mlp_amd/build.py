@@ -63,7 +63,7 @@ def _build_one(out, bdir_name, extra, force, verbose):
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(cc, jobs))
     objs = [os.path.join(bdir, s[:-4] + ".o") for s in srcs]
-    if jobs or not os.path.exists(out):
+    if jobs or any(_newer(o, out) for o in objs):        # also after an object was compiled by hand
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
