@@ -398,6 +398,30 @@ def test_captured_iteration_equals_eager_bit_for_bit(T):
     assert int(res["graph"][1]["d.convs.1.num_batches_tracked"]) == 5 * n_steps
 
 
+def test_captured_iteration_at_the_benchmarked_batch(T):
+    """What bench.py times -- replays of the captured iteration at batch 128 -- against the same five iterations launched
+    eagerly: every loss of every iteration and every weight afterwards, identical bits (replays 3..5 are graph launches)."""
+    g = torch.Generator().manual_seed(4)
+    data = [torch.rand(128, 3, 64, 64, generator=g) * 2 - 1 for _ in range(5)]
+    lat = [[torch.randn(128, 128, generator=g) for _ in range(3)] for _ in range(5)]
+    res = {}
+    for mode in ("eager", "graph"):
+        tr = T.BetaVAEGANTrainer(beta=25.0, graph=(mode == "graph"), capturable=True)
+        losses = [{k: v.clone() for k, v in tr.step(data[i].cuda(), *(t.cuda() for t in lat[i])).items()} for i in range(5)]
+        if mode == "graph":
+            assert len(tr._graphs) == 1 and tr.graph
+        res[mode] = (losses, {f"{n}.{k}": v.detach().clone() for n, net in (("eg", tr.netEG), ("d", tr.netD))
+                              for k, v in net.state_dict().items()})
+        del tr
+        torch.cuda.empty_cache()
+    for i, (le, lg) in enumerate(zip(res["eager"][0], res["graph"][0])):
+        for k in le:
+            assert torch.equal(le[k], lg[k]), (i, k, float(le[k]), float(lg[k]))
+            assert bool(torch.isfinite(le[k]).all())
+    for k, v in res["eager"][1].items():
+        assert torch.equal(v, res["graph"][1][k]), k
+
+
 def test_tuned_gemm_table_is_accepted_on_this_installation(T):
     """The shipped vendor-GEMM algorithm table (tuned_gemms.py) was measured on this image: its validators match, so a
     trainer switches TunableOp on in look-up mode (no tuning at run time)."""
