@@ -90,6 +90,27 @@ def pmc_traffic(dominant, arith):
     return None, None
 
 
+def measured_mfma_rate():
+    """bf16 MFMA TFLOP/s of a bare register-operand loop of the instruction the kernels use (v_mfma_f32_32x32x16_bf16) on
+    RANDOM operands, as measured on an MI355X of this pool by scripts/mfma_peak.hip (committed: profiles/*_mfma_peak.jsonl):
+    what the matrix pipe delivers at the clock the chip holds under that load.  Informational -- `roofline.peak` stays
+    the nominal dense peak."""
+    pdir = os.path.join(ROOT, "profiles")
+    try:
+        names = sorted(f for f in os.listdir(pdir) if f.endswith("_mfma_peak.jsonl"))
+    except OSError:
+        return None, None
+    for name in reversed(names):
+        try:
+            with open(os.path.join(pdir, name)) as f:
+                rows = [json.loads(l) for l in f if l.strip()]
+            best = max(r["tflops"] for r in rows if r.get("operands") == "random" and r.get("shape") == "32x32x16")
+            return best, "profiles/" + name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
 def _median_time(fn, warm, timed):
     for _ in range(warm):
         fn()
@@ -344,6 +365,12 @@ def main():
                                "W": dominant[4], "Cout": dominant[5], "stride": dominant[6]},
                     "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(dom_ms), "launches_timed_in": dom_leg,
                     "alg_gflop_per_launch": round(conv_flops(dominant) / 1e9, 3)}
+            mrate, msrc = measured_mfma_rate()
+            if split and mrate:
+                # informational: the same achieved rate against what a bare MFMA loop reaches on random operands
+                roof["measured_mfma_rate_random_operands"] = {
+                    "bf16_tflops": mrate, "per_fp32_multiply": round(mrate / nprod, 1),
+                    "frac_of_it": round(ach / (mrate / nprod), 4), "source": msrc}
         res = {
             "metric": "celeba64_betavaegan_train_images_per_sec", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
