@@ -44,6 +44,18 @@ def test_bench_rejects_a_world_that_disagrees_with_gpus():
     assert out.returncode != 0 and "--gpus 2" in (out.stderr + out.stdout)
 
 
+def test_bench_reads_the_committed_profile_figures():
+    """The two figures bench.py takes from committed profiles rather than from the run itself: the HBM bytes per launch
+    of the dominant kernel (PMC passes) and the on-box MFMA rate on random operands (scripts/mfma_peak.hip)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    rate, src = bench.measured_mfma_rate()
+    assert src.startswith("profiles/") and os.path.exists(os.path.join(ROOT, src))
+    assert 1000.0 < rate < bench.PEAK_BF16_MFMA_TFLOPS          # a measured rate, below the nominal dense peak
+    traffic, tsrc = bench.pmc_traffic(("conv_fwd", 128, 128, 32, 32, 256, 2), "bf16x6")
+    assert traffic >= 103.9e6 and os.path.exists(os.path.join(ROOT, tsrc))      # at least the algorithmic bytes (x + y + w)
+
+
 # ------------------------------------------------------------------ per-rank latent streams
 def _latent_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
