@@ -312,23 +312,42 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl) av[set][pl] = ga[((VG_WX_ABL & 1) ? 0 : pix) * gstep + (size_t)pl * 2 * CoP];
     };
-    load_patch(c_begin);
-    store_patch(0, c_begin);
-    size_t pcur = chunk_pix(c_begin);
+    // Order of the segment's chunks: a whole share (upw chunks of one tile) starts at its chunk that is 0 (mod upw) and
+    // wraps, so that at step j EVERY such workgroup of the launch is at a chunk that is j (mod upw).  The workgroups of
+    // an XCD (A.order: neighbouring chunk ranges, all tiles) then read the same 2-6 chunks of gy at the same time --
+    // about 1 MB in a 4 MB L2 -- where shares worked off from their own first chunk kept a window of upw..64 chunks
+    // (6-12 MB) in flight and the L2 hit rate of the two big layers at 34-46 % (877 / 1085 MB from beyond L2 per
+    // launch against 117 / 167 MB of operands: profiles/r03_hbm_traffic_by_kernel.json).  Speed only: the sum over the
+    // chunks is taken in this order whatever the timing.
+    const int nch = c_end - c_begin;
+#if defined(VG_WX_PLAIN_ORDER)              // timing experiments: the previous order
+    const int rot = 0;
+#else
+    const int rot = (nch == A.upw) ? (A.upw - c_begin % A.upw) % A.upw : 0;
+#endif
+    auto chunk_at = [&](int j) -> int {
+      int i = min(j, nch - 1) + rot;
+      i -= (i >= nch) ? nch : 0;
+      return c_begin + i;
+    };
+    load_patch(chunk_at(0));
+    store_patch(0, chunk_at(0));
+    size_t pcur = chunk_pix(chunk_at(0));
 #pragma unroll
     for (int t = 0; t < PD; ++t) load_a(t, pcur + pix_off(t));
     __syncthreads();
-    for (int ch = c_begin; ch < c_end; ++ch) {
-      const int buf = (ch - c_begin) & 1;
-      const bool more = (ch + 1) < c_end;
-      const size_t pnxt = chunk_pix(ch + 1);
+    for (int j = 0; j < nch; ++j) {
+      const int chn = chunk_at(j + 1);
+      const int buf = j & 1;
+      const bool more = (j + 1) < nch;
+      const size_t pnxt = chunk_pix(chn);
 #pragma unroll
       for (int t = 0; t < C::NPIX; ++t) {
         // gy fragments PD pixels ahead (the last PD pixels of a chunk fetch the first ones of the next chunk)
         load_a((t + PD) & PD, (t + PD < C::NPIX) ? pcur + pix_off(t + PD) : pnxt + pix_off(t + PD - C::NPIX));
-        if (t == 0 && more && !(VG_WX_ABL & 2)) load_patch(ch + 1);
+        if (t == 0 && more && !(VG_WX_ABL & 2)) load_patch(chn);
         bf16x8 bv[FP][NP];
-        if (!(VG_WX_ABL & 16) || (ch == c_begin && t == 0)) {
+        if (!(VG_WX_ABL & 16) || (j == 0 && t == 0)) {
 #pragma unroll
           for (int f = 0; f < FP; ++f)
 #pragma unroll
@@ -354,7 +373,7 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
           const int rel = t - C::ST0;
           if (rel >= 0 && rel % C::STEP == 0 && rel / C::STEP < 2 * NQ) {
             const int q = (rel / C::STEP) % NQ, g = (rel / C::STEP) / NQ;
-            if (more && grp == g && !(VG_WX_ABL & 4)) store_unit(q, buf ^ 1, ch + 1);
+            if (more && grp == g && !(VG_WX_ABL & 4)) store_unit(q, buf ^ 1, chn);
           }
         }
       }
