@@ -151,7 +151,13 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
     const int ntn = A.ntiles_n, npatch = A.blocks_per_cls / ntn, full = (npatch / 8) * 8 * ntn;
     if (bid < full) {
       const int xcd = bid & 7, j = bid >> 3;
+#if defined(VG_RING_PT_INTERLEAVED)            // timing experiments: the previous map (neighbouring pixel tiles on 8 XCDs)
       pt = (j / ntn) * 8 + xcd;
+#else
+      // an XCD works through a contiguous run of pixel tiles: neighbours in the image (shared halo rows, shared cache
+      // lines of a row) follow each other through the same L2
+      pt = xcd * (npatch / 8) + j / ntn;
+#endif
       nt = j % ntn;
     } else {
       const int t = bid - full;

@@ -285,10 +285,26 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
   const size_t gstep = (size_t)2 * NP * CoP;                           // gy units per pixel
   auto pix_off = [&](int k) -> size_t { return (size_t)(k >> 3) * OW + (k & 7); };   // pixel k of a chunk
 
-  for (int u = u_begin; u < u_end;) {
+  // A share that straddles two tiles is worked off second part first: its chunks 0 .. n2-1 of the second tile at steps
+  // 0 .. n2-1, like every other workgroup's (see the chunk order below), then the end of the first tile.
+  const int u_split = (u_begin / A.chunks + 1) * A.chunks;
+#if defined(VG_WX_PLAIN_ORDER)
+  const bool two = false;
+#else
+  const bool two = u_split < u_end && u_end <= u_split + A.chunks;
+#endif
+  int u = two ? u_split : u_begin, u_lim = u_end, pass = 0, t0 = 0;
+  while (true) {
+    if (u >= u_lim) {
+      if (!two || pass) break;
+      pass = 1;
+      u = u_begin;
+      u_lim = u_split;
+      continue;
+    }
     // ---- one segment: chunks [c_begin, c_end) of one output tile
     const int tile = u / A.chunks, c_begin = u - tile * A.chunks;
-    const int c_end = min(A.chunks, c_begin + (u_end - u));
+    const int c_end = min(A.chunks, c_begin + (u_lim - u));
     u += c_end - c_begin;
     m0 = (tile % A.mtiles) * C::TCO;
     ci0 = (tile / A.mtiles) * WCIT;
@@ -312,8 +328,8 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl) av[set][pl] = ga[((VG_WX_ABL & 1) ? 0 : pix) * gstep + (size_t)pl * 2 * CoP];
     };
-    // Order of the segment's chunks: a whole share (upw chunks of one tile) starts at its chunk that is 0 (mod upw) and
-    // wraps, so that at step j EVERY such workgroup of the launch is at a chunk that is j (mod upw).  The workgroups of
+    // Order of the segment's chunks: a share starts at its chunk that is 0 (mod upw) and wraps, so that at step j EVERY
+    // workgroup of the launch is at a chunk that is j (mod upw) (exactly for a share inside one tile).  The workgroups of
     // an XCD (A.order: neighbouring chunk ranges, all tiles) then read the same 2-6 chunks of gy at the same time --
     // about 1 MB in a 4 MB L2 -- where shares worked off from their own first chunk kept a window of upw..64 chunks
     // (6-12 MB) in flight and the L2 hit rate of the two big layers at 34-46 % (877 / 1085 MB from beyond L2 per
@@ -323,7 +339,10 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
 #if defined(VG_WX_PLAIN_ORDER)              // timing experiments: the previous order
     const int rot = 0;
 #else
-    const int rot = (nch == A.upw) ? (A.upw - c_begin % A.upw) % A.upw : 0;
+    // step t0 + j of the share is at a chunk that is t0 + j (mod upw), as far as the segment allows
+    int rot = ((t0 - c_begin) % A.upw + A.upw) % A.upw;
+    rot = rot < nch ? rot : 0;
+    t0 += nch;
 #endif
     auto chunk_at = [&](int j) -> int {
       int i = min(j, nch - 1) + rot;
@@ -475,8 +494,12 @@ void make_order(const XPlan& p, unsigned short* order) {
   std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
     return ((long)a * p.upw) % p.chunks < ((long)b * p.upw) % p.chunks;
   });
-  for (int b = 0; b < p.wgs; ++b)
-    order[b] = (unsigned short)((p.wgs % 8 == 0) ? idx[(b & 7) * (p.wgs / 8) + (b >> 3)] : b);
+  // XCD k runs the launch slots k, k + 8, ...: it gets the k-th run of the sorted list (runs differ by one workgroup
+  // when the count is not a multiple of 8)
+  int start[9];
+  start[0] = 0;
+  for (int k = 0; k < 8; ++k) start[k + 1] = start[k] + (p.wgs - k + 7) / 8;
+  for (int b = 0; b < p.wgs; ++b) order[b] = (unsigned short)idx[start[b & 7] + (b >> 3)];
 }
 
 template <class C>
