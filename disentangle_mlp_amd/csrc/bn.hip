@@ -134,7 +134,13 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
   act &= 0xff;
   // `per`: elements of this channel per workgroup of THIS pass (independent of the partial pass)
   __shared__ float s_co[4];
+  // slices in descending order: the sums pass before this one went through the channel's slices in ascending order (same
+  // channel -> same XCD in both launches), so the end of the channel is what its L2 still holds
+#if defined(VG_BN_APPLY_ASCENDING)      // timing experiments: the previous order
   const int c = blockIdx.x, k = blockIdx.y;
+#else
+  const int c = blockIdx.x, k = (int)gridDim.y - 1 - (int)blockIdx.y;
+#endif
   const double count = (double)B * HW;
   if (threadIdx.x < 64) {   // wavefront 0: fixed-order reduction of the slice partials
     double s1 = 0.0, s2 = 0.0;
