@@ -41,12 +41,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak (spec)
-PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (spec); bf16x6 issues 6 of them per fp32 multiply, bf16x3 3
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 / f16 MFMA (spec); fp16x3 issues 3 of them per fp32 multiply, bf16x6 6, bf16x3 3
 ALG_GFLOP_PER_IMAGE = 20.075       # BASELINE.md section 2 (necessary passes only)
 ALG_CONV_GFLOP_PER_IMAGE = 18.488
-MFMAS_PER_PRODUCT = {"bf16x6": 6, "bf16x3": 3}
+MFMAS_PER_PRODUCT = {"fp16x3": 3, "bf16x6": 6, "bf16x3": 3}
 GRAPH_PREP_STEPS = 3               # trainer.GRAPH_WARM_STEPS eager iterations + the one that captures and replays
 ARITH_NOTE = {
+    "fp16x3": "fp32-equivalent: every fp32 operand, scaled by an exact power of two from a device-side bound of the "
+              "tensor's largest magnitude, split into fp16 hi + lo (11 + 11 significand bits, residual <= 2^-24), "
+              "3 f16 MFMAs per multiply (hi*hi, hi*lo, lo*hi), fp32 accumulate; conv rel. error vs fp64 4e-7..6e-7 "
+              "(bf16x6: 4e-7..9e-7; the fp32-input MFMA: 5e-7..1e-6); the 3-channel edge layers in bf16x6",
     "fp32": "exact fp32-input MFMA (v_mfma_f32_32x32x2_f32)",
     "bf16x6": "fp32-equivalent: every fp32 operand split exactly into 3 bf16 planes (8+8+8 mantissa bits), 6 bf16 "
               "MFMAs per multiply (all plane pairs whose index sum < 3), fp32 accumulate; conv rel. error vs fp64 "
@@ -90,21 +94,25 @@ def pmc_traffic(dominant, arith):
     return None, None
 
 
-def measured_mfma_rate():
-    """bf16 MFMA TFLOP/s of a bare register-operand loop of the instruction the kernels use (v_mfma_f32_32x32x16_bf16) on
-    RANDOM operands, as measured on an MI355X of this pool by scripts/mfma_peak.hip (committed: profiles/*_mfma_peak.jsonl):
-    what the matrix pipe delivers at the clock the chip holds under that load.  Informational -- `roofline.peak` stays
-    the nominal dense peak."""
+def measured_mfma_rate(arith="bf16x6"):
+    """16-bit MFMA TFLOP/s of a bare register-operand loop of the instruction the kernels use (v_mfma_f32_32x32x16_f16
+    for fp16x3, _bf16 otherwise) on RANDOM operands, as measured on an MI355X of this pool by scripts/mfma_f16.hip /
+    scripts/mfma_peak.hip (committed: profiles/*_mfma_f16.jsonl, *_mfma_peak.jsonl): what the matrix pipe delivers at the
+    clock the chip holds under that load.  Informational -- `roofline.peak` stays the nominal dense peak."""
     pdir = os.path.join(ROOT, "profiles")
+    f16 = arith == "fp16x3"
     try:
-        names = sorted(f for f in os.listdir(pdir) if f.endswith("_mfma_peak.jsonl"))
+        names = sorted(f for f in os.listdir(pdir) if f.endswith("_mfma_f16.jsonl" if f16 else "_mfma_peak.jsonl"))
     except OSError:
         return None, None
     for name in reversed(names):
         try:
             with open(os.path.join(pdir, name)) as f:
                 rows = [json.loads(l) for l in f if l.strip()]
-            best = max(r["tflops"] for r in rows if r.get("operands") == "random" and r.get("shape") == "32x32x16")
+            if f16:
+                best = max(r["tflops"] for r in rows if r.get("operands") == "random" and r.get("mfma") == "32x32x16_f16")
+            else:
+                best = max(r["tflops"] for r in rows if r.get("operands") == "random" and r.get("shape") == "32x32x16")
             return best, "profiles/" + name
         except (OSError, KeyError, ValueError):
             continue
@@ -233,6 +241,9 @@ def main():
     B = args.batch
     arith = ops.CONV_ARITH               # the product default unless VG_CONV_ARITH was exported
     tr = BetaVAEGANTrainer(device=dev, seed=999, beta=args.beta)
+    ck0 = tr.checkpoint(0)               # the initial state (the reference's seed recipe), cloned: reloaded before the warm-up
+    ck0 = {k: ({n: t.clone() for n, t in v.items()} if k.endswith("_model") else __import__("copy").deepcopy(v))
+           for k, v in ck0.items()}
     g = torch.Generator().manual_seed(1234 + rank)            # each rank its own shard
     data = (torch.rand(B, 3, 64, 64, generator=g) * 2 - 1).to(dev)
     noise = [torch.randn(B, 128, generator=g).to(dev) for _ in range(3)]
@@ -275,6 +286,11 @@ def main():
     totals = {k: sum(v) for k, v in per_key.items()}
     dominant = max(totals, key=totals.get) if totals else None
     conv_ms_profiled = sum(totals.values())
+    # The preparation above has already trained for prep_steps iterations on this one synthetic batch, and on it the
+    # discriminator saturates within a few iterations (the fake path's gradients then underflow and their launches
+    # run on near-zero operands, which the chip clocks higher): go back to the initial weights and optimizer state, in
+    # place (the captured graph stays valid), so that warm-up and timed steps are iterations 0 .. W + K - 1 of training.
+    tr.load_in_place(ck0)
     for i in range(args.warmup):
         one_step()
 
@@ -289,6 +305,16 @@ def main():
     host_ms = timed_steps.host_ms
     dom_ms = ops.stop_timing().get(dominant, []) if not graphed else []
     out = {k: v.clone() for k, v in out.items()}
+    # what regime the last timed step ran in: mean D(x), and how much of the gradient that D sends back into the decoder
+    # through the generated batch is exactly zero (one probed -- eager -- iteration right after the timed region)
+    regime = {"D_x_mean_last_timed_step": round(float(out["D_x_sum"]) / B, 6),
+              "iterations_since_initial_weights": args.warmup + args.steps}
+    def _probe(name, gten):
+        regime["fake_path_gy_zero_fraction"] = round(float((gten == 0).float().mean()), 6)
+        regime["fake_path_gy_absmax"] = float(gten.abs().max())
+    tr.probe = _probe
+    one_step()
+    tr.probe = None
     comm = None
     if world > 1:
         ranks = torch.ones(1, device=dev)
@@ -315,7 +341,7 @@ def main():
     if world == 1 and not args.no_opt_in:
         other = {}
         try:
-            for mode in ("fp32", "bf16x6", "bf16x3"):
+            for mode in ("fp32", "bf16x6", "bf16x3", "fp16x3"):
                 if mode == arith:
                     continue
                 ops.CONV_ARITH = mode
@@ -359,17 +385,17 @@ def main():
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                     "traffic_source": tsrc, "kernel": kname,
-                    "peak_note": ("dense bf16 MFMA 2500 TFLOP/s / %d MFMAs per fp32 multiply" % nprod) if split
+                    "peak_note": ("dense 16-bit MFMA 2500 TFLOP/s / %d MFMAs per fp32 multiply" % nprod) if split
                     else "fp32-input MFMA = fp32 vector peak",
                     "launch": {"op": dominant[0], "B": dominant[1], "Cin": dominant[2], "H": dominant[3],
                                "W": dominant[4], "Cout": dominant[5], "stride": dominant[6]},
                     "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(dom_ms), "launches_timed_in": dom_leg,
                     "alg_gflop_per_launch": round(conv_flops(dominant) / 1e9, 3)}
-            mrate, msrc = measured_mfma_rate()
+            mrate, msrc = measured_mfma_rate(arith)
             if split and mrate:
                 # informational: the same achieved rate against what a bare MFMA loop reaches on random operands
                 roof["measured_mfma_rate_random_operands"] = {
-                    "bf16_tflops": mrate, "per_fp32_multiply": round(mrate / nprod, 1),
+                    "mfma_tflops": mrate, "per_fp32_multiply": round(mrate / nprod, 1),
                     "frac_of_it": round(ach / (mrate / nprod), 4), "source": msrc}
         res = {
             "metric": "celeba64_betavaegan_train_images_per_sec", "value": round(value, 2), "unit": "images/s",
@@ -381,8 +407,9 @@ def main():
             "untimed_preparation_steps": prep_steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32" if arith == "fp32" else
-                     "fp32-equivalent (%s split of fp32 operands on the bf16 MFMA, fp32 accumulate, every convolution; "
-                     "Linear layers, BatchNorm, losses, Adam in fp32)" % arith if arith == "bf16x6" else
+                     "fp32-equivalent (%s split of fp32 operands on the %s MFMA, fp32 accumulate, every convolution; "
+                     "Linear layers, BatchNorm, losses, Adam in fp32)" % (arith, "f16" if arith == "fp16x3" else "bf16")
+                     if arith in ("bf16x6", "fp16x3") else
                      arith + " (split-bf16 operands on the bf16 MFMA, fp32 accumulate) + fp32 elsewhere",
             "arithmetic": ARITH_NOTE[arith],
             "data": "synthetic",
@@ -400,6 +427,7 @@ def main():
                 PEAK_BF16_MFMA_TFLOPS / MFMAS_PER_PRODUCT[arith] if arith in MFMAS_PER_PRODUCT else PEAK_FP32_MFMA_TFLOPS), 4),
             "conv_ms_per_step_profiled": round(conv_ms_profiled, 3),
             "losses_finite": finite,
+            "regime": regime,
         }
         if comm is not None:
             res["data_parallel"] = comm

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvaegan_hip.so")
-ABI_VERSION = 3      # VG_ABI_VERSION of include/vaegan_hip.h this binding was written against
+ABI_VERSION = 4      # VG_ABI_VERSION of include/vaegan_hip.h this binding was written against
 
 _P, _I, _F, _Z = c_void_p, c_int, c_float, c_size_t
 
@@ -30,7 +30,10 @@ SIGNATURES = {
     "vg_conv5x5_fwd_packed_stats_floats": (_Z, [_I, _I, _I, _I, _I, _I]),
     "vg_conv5x5_fwd_packed_stats": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "vg_conv5x5_packed_bf16split_bytes": (_Z, [_I, _I, _I]),
-    "vg_conv5x5_pack_bf16split": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "vg_conv5x5_pack_bf16split": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "vg_absmax": (_I, [_P, _Z, _P, _P]),
+    "vg_absmax_affine": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "vg_absmax_multi": (_I, [_P, _I, _P]),
     "vg_conv5x5_pack_bf16split_multi": (_I, [_P, _I, _I, _P]),
     "vg_convT5x5_fwd_bf16split_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "vg_convT5x5_fwd_bf16split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P]),
@@ -47,16 +50,16 @@ SIGNATURES = {
     "vg_convT5x5_s1_thin_bf16split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "vg_conv5x5_fwd_bf16split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P]),
     "vg_conv5x5_wgrad_bf16split_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
-    "vg_conv5x5_wgrad_bf16split": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _I, _I, _I, _P]),
+    "vg_conv5x5_wgrad_bf16split": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _I, _I, _P, _P, _I, _P]),
     "vg_conv5x5_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "vg_conv5x5_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _I, _P]),
     "vg_channel_sum": (_I, [_P, _P, _I, _I, _I, _P, _Z, _P]),
     "vg_bn_workspace_bytes": (_Z, [_I]),
     "vg_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P, _Z, _P]),
-    "vg_bn_act_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
-    "vg_bn_finalize_stats": (_I, [_P, _I, _I, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _Z, _P]),
-    "vg_bn_stats": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _Z, _P]),
-    "vg_affine_act": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vg_bn_act_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
+    "vg_bn_finalize_stats": (_I, [_P, _I, _I, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _Z, _P]),
+    "vg_bn_stats": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _Z, _P]),
+    "vg_affine_act": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "vg_bias_act_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "vg_act_bwd": (_I, [_P, _P, _P, _Z, _I, _P]),
     "vg_reparam_kl_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
@@ -149,13 +152,18 @@ class use_tuning:
 class ConvFusion(ctypes.Structure):
     """vg_conv_fusion of include/vaegan_hip.h."""
     _fields_ = [("in_scale", c_void_p), ("in_shift", c_void_p), ("in_act", c_int), ("stats", c_void_p),
-                ("stats_floats", c_size_t)]
+                ("stats_floats", c_size_t), ("in_amax", c_void_p)]
 
 
 class PackEntry(ctypes.Structure):
     """VgPackEntry of include/vaegan_hip.h."""
     _fields_ = [("w", c_void_p), ("packed", c_void_p), ("Cout", c_int), ("Cin", c_int), ("transposed", c_int),
-                ("stride", c_int)]
+                ("stride", c_int), ("w_amax", c_void_p)]
+
+
+class AbsmaxEntry(ctypes.Structure):
+    """VgAbsmaxEntry of include/vaegan_hip.h."""
+    _fields_ = [("x", c_void_p), ("n", c_size_t), ("amax", c_void_p)]
 
 
 class HipKernelError(RuntimeError):

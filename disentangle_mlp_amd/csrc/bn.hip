@@ -129,7 +129,10 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
                                                       float* __restrict__ running_mean,
                                                       float* __restrict__ running_var, float* __restrict__ dgamma,
                                                       float* __restrict__ dbeta, float* __restrict__ out, int B,
-                                                      int C, int HW, long per, float eps, float momentum, int act) {
+                                                      int C, int HW, long per, float eps, float momentum, int act,
+                                                      unsigned* __restrict__ out_amax) {
+  // out_amax (backward, may be NULL): max |gx| is added to it (common.hpp block_amax_atomic) -- the bound the fp16-plane
+  // convolutions that consume gx scale it by, emitted here instead of by a pass of its own
   const bool accp = (act & 0x100) != 0;        // backward: dgamma / dbeta are accumulated into (bit 8 of `act`)
   act &= 0xff;
   // `per`: elements of this channel per workgroup of THIS pass (independent of the partial pass)
@@ -190,11 +193,14 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
     mu = mean_io[c];
     is = invstd_io[c];
   }
+  unsigned am = 0;
   auto one = [&](float xv, float gv) -> float {
     const float pre = fmaf(xv, sc, sh);
     if (!BWD) return act_fwd(pre, act);
     const float g = act_grad(pre, gv, act);
-    return sc * (g - c1 - ((xv - mu) * is) * c2);
+    const float r = sc * (g - c1 - ((xv - mu) * is) * c2);
+    am = max(am, abs_bits(r));
+    return r;
   };
   const long total = (long)B * HW;
   const long v0 = (long)k * per, v1 = min(v0 + per, total);
@@ -220,6 +226,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
       out[off] = one(x[off], BWD ? gy[off] : 0.f);
     }
   }
+  if (BWD && out_amax) block_amax_atomic<NT>(am, out_amax);      // wave-uniform condition
 }
 
 // Backward in ONE pass for channels that fit a workgroup's registers (B * HW <= ONE_NT * 4 * NV elements: the 16 x 16 and
@@ -236,7 +243,8 @@ __global__ __launch_bounds__(ONE_NT) void bn_bwd_onepass_kernel(const float* __r
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, float* __restrict__ gx,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                int B, int C, int HW, int act) {
+                                                                int B, int C, int HW, int act,
+                                                                unsigned* __restrict__ gx_amax) {
   __shared__ double red[ONE_NT / 64];
   __shared__ float s_c[2];
   const bool accp = (act & 0x100) != 0;
@@ -281,6 +289,7 @@ __global__ __launch_bounds__(ONE_NT) void bn_bwd_onepass_kernel(const float* __r
   }
   __syncthreads();
   const float c1 = s_c[0], c2 = s_c[1];
+  unsigned am = 0;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     if ((j * ONE_NT + (int)threadIdx.x) * 4 >= total) continue;
@@ -291,8 +300,10 @@ __global__ __launch_bounds__(ONE_NT) void bn_bwd_onepass_kernel(const float* __r
     o.y = sc * (gp[1] - c1 - ((xp[1] - mu) * is) * c2);
     o.z = sc * (gp[2] - c1 - ((xp[2] - mu) * is) * c2);
     o.w = sc * (gp[3] - c1 - ((xp[3] - mu) * is) * c2);
+    am = max(max(am, abs_bits(o.x)), max(max(abs_bits(o.y), abs_bits(o.z)), abs_bits(o.w)));
     *reinterpret_cast<float4*>(gx + off[j]) = o;
   }
+  if (gx_amax) block_amax_atomic<ONE_NT>(am, gx_amax);      // max |gx| for the fp16-plane consumers (bn_apply_kernel)
 }
 
 // BatchNorm1d: x [B][C].  A workgroup owns 32 consecutive channels (128-byte coalesced rows);
@@ -359,7 +370,7 @@ __global__ __launch_bounds__(NT) void bn1d_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ mean,
                                                       const float* __restrict__ invstd, float* __restrict__ gx,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int B,
-                                                      int C, int act) {
+                                                      int C, int act, unsigned* __restrict__ gx_amax) {
   const bool accp = (act & 0x100) != 0;        // as bn_apply_kernel
   act &= 0xff;
   __shared__ double r1[B1_SL][B1_CH], r2[B1_SL][B1_CH];
@@ -398,15 +409,19 @@ __global__ __launch_bounds__(NT) void bn1d_bwd_kernel(const float* __restrict__ 
     s_c2[cl] = (float)(t2 / B);
   }
   __syncthreads();
+  unsigned am = 0;
   if (cok) {
     const float c1 = s_c1[cl], c2 = s_c2[cl];
     for (int b = sl; b < B; b += B1_SL) {
       const size_t o = (size_t)b * C + c;
       const float xv = x[o];
       const float g = act_grad(fmaf(xv, sc, sh), gy[o], act);
-      gx[o] = sc * (g - c1 - ((xv - mu) * is) * c2);
+      const float r = sc * (g - c1 - ((xv - mu) * is) * c2);
+      am = max(am, abs_bits(r));
+      gx[o] = r;
     }
   }
+  if (gx_amax) block_amax_atomic<NT>(am, gx_amax);
 }
 
 // slices of the apply pass: >= 4096 elements per workgroup so that the per-workgroup prologue (partials
@@ -440,7 +455,10 @@ __global__ __launch_bounds__(NT) void bn_finalize_kernel(const T* __restrict__ p
                                                          const float* __restrict__ beta, float* __restrict__ running_mean,
                                                          float* __restrict__ running_var, float* __restrict__ mean_out,
                                                          float* __restrict__ invstd_out, float* __restrict__ scale,
-                                                         float* __restrict__ shift, float eps, float momentum) {
+                                                         float* __restrict__ shift, float eps, float momentum,
+                                                         unsigned* __restrict__ act_amax) {
+  // act_amax (may be NULL): an upper bound of max |act(BN(x))| over the whole tensor is added to it (atomic maximum of
+  // the channels' bounds) -- what the fp16-plane convolution that applies these coefficients on load scales its input by
   // 32 channels per workgroup x 8 partial-lanes: consecutive threads read consecutive channels (the convolution's
   // slots are [slot][C][2]: 256 contiguous bytes per 32 threads), each partial-lane sums every 8th partial, and the 8
   // sums of a channel are added in a fixed order
@@ -474,6 +492,10 @@ __global__ __launch_bounds__(NT) void bn_finalize_kernel(const T* __restrict__ p
     invstd_out[c] = is;
     scale[c] = sc;
     shift[c] = beta[c] - mu * sc;
+    if (act_amax) {      // Chebyshev: |x - mean| <= sigma sqrt(n - 1), so |BN(x)| <= |gamma| sqrt(n) + |beta| (+ fp32 rounding of x * sc + sh)
+      const float bound = (fabsf(gamma[c]) * sqrtf((float)count) + fabsf(beta[c])) * 1.001f + fabsf(mu * sc) * 1e-6f;
+      atomicMax(act_amax, __float_as_uint(bound));
+    }
     if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
     if (running_var) {
       const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
@@ -492,7 +514,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_wide_kernel(const float* __r
                                                                 float* __restrict__ running_mean,
                                                                 float* __restrict__ running_var, float* __restrict__ mean_out,
                                                                 float* __restrict__ invstd_out, float* __restrict__ scale,
-                                                                float* __restrict__ shift, float eps, float momentum) {
+                                                                float* __restrict__ shift, float eps, float momentum,
+                                                                unsigned* __restrict__ act_amax) {
   constexpr int CH = 8, KL = 128;
   __shared__ double r1[KL][CH], r2[KL][CH];
   const int cl = threadIdx.x % CH, kl = threadIdx.x / CH;
@@ -539,6 +562,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_wide_kernel(const float* __r
     invstd_out[c] = is;
     scale[c] = sc;
     shift[c] = beta[c] - mu * sc;
+    if (act_amax) {      // Chebyshev: |x - mean| <= sigma sqrt(n - 1), so |BN(x)| <= |gamma| sqrt(n) + |beta| (+ fp32 rounding of x * sc + sh)
+      const float bound = (fabsf(gamma[c]) * sqrtf((float)count) + fabsf(beta[c])) * 1.001f + fabsf(mu * sc) * 1e-6f;
+      atomicMax(act_amax, __float_as_uint(bound));
+    }
     if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
     if (running_var) {
       const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
@@ -584,9 +611,10 @@ __global__ __launch_bounds__(NT) void stats_partial_kernel(const float* __restri
 // the 64-bit division per thread that this replaces made the pass run at 0.8 TB/s (20 us for 16 MB).
 __global__ __launch_bounds__(NT) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, float* __restrict__ y, int C,
-                                                        int HW, size_t n4, int act, int hw4_shift) {
-  const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
-  if (i >= n4) return;
+                                                        int HW, size_t n4, int act, int hw4_shift,
+                                                        unsigned* __restrict__ y_amax) {
+  const size_t i0 = (size_t)blockIdx.x * NT + threadIdx.x;
+  const size_t i = i0 < n4 ? i0 : n4 - 1;                   // the tail threads redo the last unit (they take part in the maximum)
   const size_t e = 4 * i;
   // HW % 4 == 0: the four elements share a channel
   const int c = hw4_shift >= 0 ? (int)((unsigned)(i >> hw4_shift) % (unsigned)C) : (int)((e / HW) % C);
@@ -597,17 +625,22 @@ __global__ __launch_bounds__(NT) void affine_act_kernel(const float* __restrict_
   o.y = act_fwd(fmaf(v.y, sc, sh), act);
   o.z = act_fwd(fmaf(v.z, sc, sh), act);
   o.w = act_fwd(fmaf(v.w, sc, sh), act);
-  *reinterpret_cast<float4*>(y + e) = o;
+  if (i0 < n4) *reinterpret_cast<float4*>(y + e) = o;
+  if (y_amax)      // max |y| for an fp16-plane consumer (common.hpp block_amax_atomic)
+    block_amax_atomic<NT>(max(max(abs_bits(o.x), abs_bits(o.y)), max(abs_bits(o.z), abs_bits(o.w))), y_amax);
 }
 
 // the same for H*W not a multiple of 4 (odd image sizes): one element per lane
 __global__ __launch_bounds__(NT) void affine_act_scalar_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, float* __restrict__ y,
-                                                               int C, int HW, size_t n, int act) {
-  const size_t e = (size_t)blockIdx.x * NT + threadIdx.x;
-  if (e >= n) return;
+                                                               int C, int HW, size_t n, int act,
+                                                               unsigned* __restrict__ y_amax) {
+  const size_t e0 = (size_t)blockIdx.x * NT + threadIdx.x;
+  const size_t e = e0 < n ? e0 : n - 1;
   const int c = (int)((e / HW) % C);
-  y[e] = act_fwd(fmaf(x[e], scale[c], shift[c]), act);
+  const float r = act_fwd(fmaf(x[e], scale[c], shift[c]), act);
+  if (e0 < n) y[e] = r;
+  if (y_amax) block_amax_atomic<NT>(abs_bits(r), y_amax);
 }
 
 extern "C" size_t vg_bn_workspace_bytes(int C) { return C > 0 ? ws_bytes(C) : 0; }
@@ -615,7 +648,8 @@ extern "C" size_t vg_bn_workspace_bytes(int C) { return C > 0 ? ws_bytes(C) : 0;
 extern "C" int vg_bn_finalize_stats(const float* stats, int nslots, int C, double count, const float* gamma,
                                     const float* beta, float* running_mean, float* running_var, float* save_mean,
                                     float* save_invstd, float* scale, float* shift, float eps, float momentum,
-                                    void* workspace, size_t workspace_bytes, void* stream) {
+                                    float* act_amax, void* workspace, size_t workspace_bytes, void* stream) {
+  unsigned* am = (unsigned*)act_amax;
   if (!stats || nslots <= 0 || C <= 0 || count <= 0 || !gamma || !beta || !save_mean || !save_invstd || !scale || !shift)
     return VG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -625,13 +659,13 @@ extern "C" int vg_bn_finalize_stats(const float* stats, int nslots, int C, doubl
   if (nslots <= 64) {
     hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(cdiv(C, 32)), dim3(NT), 0, st, stats, nslots, 1L, (long)C, C,
                        count, gamma, beta, running_mean, running_var, save_mean, save_invstd, scale, shift, eps,
-                       momentum);      // stats[slot][C][2]: channel stride 1, slot stride C
+                       momentum, am);      // stats[slot][C][2]: channel stride 1, slot stride C
     VG_CHECK_LAUNCH();
     return 0;
   }
   if (nslots <= 4096) {
     hipLaunchKernelGGL(bn_finalize_wide_kernel, dim3(cdiv(C, 8)), dim3(1024), 0, st, stats, nslots, C, count, gamma, beta,
-                       running_mean, running_var, save_mean, save_invstd, scale, shift, eps, momentum);
+                       running_mean, running_var, save_mean, save_invstd, scale, shift, eps, momentum, am);
     VG_CHECK_LAUNCH();
     return 0;
   }
@@ -641,15 +675,15 @@ extern "C" int vg_bn_finalize_stats(const float* stats, int nslots, int C, doubl
   VG_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, 32)), dim3(NT), 0, st, (const double*)part, NS_MAX,
                      (long)NS_MAX, 1L, C, count, gamma, beta, running_mean, running_var, save_mean, save_invstd, scale,
-                     shift, eps, momentum);      // part[c][NS_MAX][2]
+                     shift, eps, momentum, am);      // part[c][NS_MAX][2]
   VG_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int vg_bn_stats(const float* x, const float* gamma, const float* beta, float* running_mean,
                            float* running_var, float* save_mean, float* save_invstd, float* scale, float* shift, int B,
-                           int C, int HW, float eps, float momentum, void* workspace, size_t workspace_bytes,
-                           void* stream) {
+                           int C, int HW, float eps, float momentum, float* act_amax, void* workspace,
+                           size_t workspace_bytes, void* stream) {
   if (!x || !gamma || !beta || !save_mean || !save_invstd || !scale || !shift || B <= 0 || C <= 0 || HW <= 0)
     return VG_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < ws_bytes(C)) return VG_ERR_WORKSPACE;
@@ -661,20 +695,20 @@ extern "C" int vg_bn_stats(const float* x, const float* gamma, const float* beta
   VG_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, 32)), dim3(NT), 0, st, (const double*)part, s.ns,
                      (long)s.ns, 1L, C, (double)B * HW, gamma, beta, running_mean, running_var, save_mean, save_invstd,
-                     scale, shift, eps, momentum);      // part[c][ns][2]
+                     scale, shift, eps, momentum, (unsigned*)act_amax);      // part[c][ns][2]
   VG_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int vg_affine_act(const float* x, const float* scale, const float* shift, float* y, int B, int C, int HW,
-                             int act, void* stream) {
+                             int act, float* y_amax, void* stream) {
   if (!x || !scale || !shift || !y || B <= 0 || C <= 0 || HW <= 0) return VG_ERR_BAD_ARG;
   if (act < VG_ACT_NONE || act > VG_ACT_LRELU) return VG_ERR_BAD_ARG;
   if (HW & 3) {
     const size_t n = (size_t)B * C * HW;
     if (cdiv((long)n, (long)NT) > 0x7fffffffL) return VG_ERR_BAD_ARG;
     hipLaunchKernelGGL(affine_act_scalar_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, x,
-                       scale, shift, y, C, HW, n, act);
+                       scale, shift, y, C, HW, n, act, (unsigned*)y_amax);
     VG_CHECK_LAUNCH();
     return 0;
   }
@@ -688,7 +722,7 @@ extern "C" int vg_affine_act(const float* x, const float* scale, const float* sh
     if ((n4 >> sh) > 0xffffffffULL) sh = -1;
   }
   hipLaunchKernelGGL(affine_act_kernel, dim3((unsigned)((n4 + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, x, scale,
-                     shift, y, C, HW, n4, act, sh);
+                     shift, y, C, HW, n4, act, sh, (unsigned*)y_amax);
   VG_CHECK_LAUNCH();
   return 0;
 }
@@ -716,15 +750,16 @@ extern "C" int vg_bn_act_fwd(const float* x, const float* gamma, const float* be
   const Slicing a = make_apply_slicing(B, C, HW);
   hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(C, a.ns), dim3(NT), 0, st, x, (const float*)nullptr,
                      (const double*)part, s.ns, gamma, beta, save_mean, save_invstd, running_mean, running_var,
-                     (float*)nullptr, (float*)nullptr, y, B, C, HW, a.per, eps, momentum, act);
+                     (float*)nullptr, (float*)nullptr, y, B, C, HW, a.per, eps, momentum, act, (unsigned*)nullptr);
   VG_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int vg_bn_act_bwd(const float* gy, const float* x, const float* gamma, const float* beta,
                              const float* save_mean, const float* save_invstd, float* gx, float* dgamma,
-                             float* dbeta, int B, int C, int HW, int act, int accumulate_param_grads, void* workspace,
-                             size_t workspace_bytes, void* stream) {
+                             float* dbeta, int B, int C, int HW, int act, int accumulate_param_grads, float* gx_amax,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  unsigned* am = (unsigned*)gx_amax;
   if (!gy || !x || !gamma || !beta || !save_mean || !save_invstd || !gx || B <= 0 || C <= 0 || HW <= 0)
     return VG_ERR_BAD_ARG;
   if (act < VG_ACT_NONE || act > VG_ACT_LRELU) return VG_ERR_BAD_ARG;
@@ -732,7 +767,7 @@ extern "C" int vg_bn_act_bwd(const float* gy, const float* x, const float* gamma
   const int act_apply = act | (accumulate_param_grads ? 0x100 : 0);      // bit 8: dgamma / dbeta += (kernels decode it)
   if (HW == 1) {
     hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(cdiv(C, B1_CH)), dim3(NT), 0, st, gy, x, gamma, beta, save_mean,
-                       save_invstd, gx, dgamma, dbeta, B, C, act_apply);
+                       save_invstd, gx, dgamma, dbeta, B, C, act_apply, am);
     VG_CHECK_LAUNCH();
     return 0;
   }
@@ -746,10 +781,10 @@ extern "C" int vg_bn_act_bwd(const float* gy, const float* x, const float* gamma
   if (one_pass && (HW & 3) == 0 && per_channel >= 4 && per_channel <= (long)ONE_NT * 4 * 8 && C >= 128) {
     if (per_channel <= (long)ONE_NT * 4 * 2)
       hipLaunchKernelGGL(bn_bwd_onepass_kernel<2>, dim3(C), dim3(ONE_NT), 0, st, x, gy, gamma, beta, save_mean, save_invstd,
-                         gx, dgamma, dbeta, B, C, HW, act_apply);
+                         gx, dgamma, dbeta, B, C, HW, act_apply, am);
     else
       hipLaunchKernelGGL(bn_bwd_onepass_kernel<8>, dim3(C), dim3(ONE_NT), 0, st, x, gy, gamma, beta, save_mean, save_invstd,
-                         gx, dgamma, dbeta, B, C, HW, act_apply);
+                         gx, dgamma, dbeta, B, C, HW, act_apply, am);
     VG_CHECK_LAUNCH();
     return 0;
   }
@@ -762,7 +797,7 @@ extern "C" int vg_bn_act_bwd(const float* gy, const float* x, const float* gamma
   const Slicing a = make_apply_slicing(B, C, HW);
   hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(C, a.ns), dim3(NT), 0, st, x, gy, (const double*)part, s.ns, gamma,
                      beta, const_cast<float*>(save_mean), const_cast<float*>(save_invstd), (float*)nullptr,
-                     (float*)nullptr, dgamma, dbeta, gx, B, C, HW, a.per, 0.f, 0.f, act_apply);
+                     (float*)nullptr, dgamma, dbeta, gx, B, C, HW, a.per, 0.f, 0.f, act_apply, am);
   VG_CHECK_LAUNCH();
   return 0;
 }

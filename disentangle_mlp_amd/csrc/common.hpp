@@ -36,6 +36,72 @@ __device__ __forceinline__ int acc_row(int r, int lane) {
   return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
 }
 
+// Activation applied on load: identity (slope 1), ReLU (0), LeakyReLU (0.2).  One compare, one select, one multiply,
+// no branch -- and a NaN stays a NaN, as in torch (fmaxf / fminf drop it: max(NaN, 0) = 0).
+__device__ __forceinline__ float act_slope(float v, float slope) { return v * (v > 0.f ? 1.f : slope); }
+
+// ---- split arithmetics of the convolution kernels -------------------------------------------
+// An fp32 operand becomes NP 16-bit planes; the plane products whose indices sum to < NP go to the 16-bit MFMA with
+// fp32 accumulation.  bf16 planes (F16 = false): each plane takes the leading 8 significand bits of what is left --
+// 3 planes are the whole fp32 significand, full fp32 range, 6 products.  fp16 planes (F16 = true, NP = 2): hi + lo carry
+// 11 + 11 significand bits (residual <= 2^-24 relative), 3 products; fp16 has 5 exponent bits, so the operand is first
+// multiplied by an exact power of two that puts the tensor's largest magnitude just under 2^15 (f16_scale_of of an
+// UPPER BOUND of max|x| read from device memory), and the product of the two operands' inverse scales is applied to
+// the fp32 accumulators at the end.  Elements more than 2^-16 below the bound keep fewer than 22 bits (the lo plane
+// runs into fp16's subnormals, which the MFMA honours: profiles/r04_mfma_f16.jsonl): their error is bounded by 2^-40
+// of the tensor's bound instead of 2^-24 of themselves.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+#define VG_PLANES_F16_FLAG 0x100      // == VG_PLANES_F16 of vaegan_hip.h
+
+// biased fp32 exponent of an upper bound `amax` >= 0, clamped so that both 2^(14 - E) and 2^(E - 14) are normal fp32
+// numbers (amax = 0 or subnormal: the largest scale; inf / NaN: the smallest -- the data then carries the inf / NaN)
+__device__ __forceinline__ unsigned f16_bound_exp(float amax) {
+  const unsigned e = (__float_as_uint(amax) >> 23) & 0xffu;
+  return min(max(e, 15u), 254u);
+}
+// amax in [2^E, 2^(E+1))  ->  2^(14 - E): the scaled tensor lies in (-2^15, 2^15), fp16's largest finite value is 65504
+__device__ __forceinline__ float f16_scale_of(float amax) { return __uint_as_float((268u - f16_bound_exp(amax)) << 23); }
+__device__ __forceinline__ float f16_unscale_of(float amax) { return __uint_as_float((f16_bound_exp(amax) - 14u) << 23); }
+
+// v[8] (already scaled when F16) -> NP planes as raw 16-byte units; v is consumed
+template <int NP, bool F16>
+__device__ __forceinline__ void split_planes16(float* v, f32x4* out) {
+  if constexpr (F16) {
+    static_assert(NP == 2, "fp16 planes: hi + lo");
+    f16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const _Float16 h = (_Float16)v[j];          // round to nearest even: |v - h| <= 2^-12 |v|
+      hi[j] = h;
+      lo[j] = (_Float16)(v[j] - (float)h);        // exact difference, rounded to 11 more bits
+    }
+    out[0] = __builtin_bit_cast(f32x4, hi);
+    out[1] = __builtin_bit_cast(f32x4, lo);
+  } else {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {                // hi, (mid,) lo: each plane takes the leading 8 bits of what is left
+      bf16x8 q;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)v[j];
+        q[j] = h;
+        v[j] -= (float)h;
+      }
+      out[p] = __builtin_bit_cast(f32x4, q);
+    }
+  }
+}
+
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_split16(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // ---- wavefront / block reductions (64 lanes; no 32-lane idioms) -------------
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
@@ -68,6 +134,26 @@ __device__ __forceinline__ T block_sum(T v, T* red) {
   return t;
 }
 
+// Bound of max |x| for the fp16-plane arithmetic: bit pattern of |v| (integer order == float order for non-negative
+// floats; NaN patterns sort above every number), and the workgroup's maximum added to a device word with ONE atomic
+// (order-independent: deterministic).  Every thread of the NT-thread workgroup must call it.
+__device__ __forceinline__ unsigned abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+
+template <int NT>
+__device__ __forceinline__ void block_amax_atomic(unsigned m, unsigned* out) {
+  __shared__ unsigned amax_red[NT / 64];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) amax_red[wid] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) m = max(m, amax_red[i]);
+    if (m) atomicMax(out, m);
+  }
+}
+
 __host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // cross-file internal entry points (not part of the C ABI)
@@ -77,7 +163,8 @@ size_t vg_internal_ring_workspace_bytes(int mode, int B, int Cin, int H, int W, 
 size_t vg_internal_ring_stats_floats(int mode, int B, int Cin, int H, int W, int Cout);
 int vg_internal_ring_conv(int mode, const float* x, const void* packed, const float* bias, float* y, int B, int Cin, int H,
                           int W, int Cout, int planes, void* workspace, size_t workspace_bytes, const float* in_scale,
-                          const float* in_shift, int in_act, float* stats, size_t stats_floats, hipStream_t st);
+                          const float* in_shift, int in_act, float* stats, size_t stats_floats, const float* in_amax,
+                          hipStream_t st);       // planes may carry VG_PLANES_F16 (then in_amax is required)
 #ifdef VG_TUNING
 void vg_internal_ring_set_variant(int v);
 void vg_internal_wx_set_th(int th);

@@ -28,10 +28,9 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-
 enum { X_FWD = 0, X_TR = 1 };
 constexpr int XNT = 256;
+constexpr int VG_PACK_SPARE = 3;   // zero steps behind a pack (the ring kernel's DMA runs three steps ahead)
 
 // 16-byte units per patch row (FWD stride 2: per column parity).  Chosen so that the patch rows a
 // 32-pixel fragment spans start on disjoint groups of 16 units (= 256 B, one LDS bank row):
@@ -50,10 +49,12 @@ constexpr int row_units(int mode, int S, int TW, int PW) {
 // WC x WP wavefronts (WC * WP = 4), FC x FP fragments each: cout tile 32*WC*FC, pixel tile 32*WP*FP
 // NP_: operand planes -- 2: hi/lo split, 3 products ("bf16x3", ~4.5e-6); 3: exact hi/mid/lo split of the fp32
 // mantissa (8 + 8 + 8 bits), 6 products, every dropped term below 2^-24 ("bf16x6", fp32-equivalent)
-template <int MODE_, int S_, int NB_, int TH_, int TW_, int WC_, int FC_, int FP_, int NP_>
+template <int MODE_, int S_, int NB_, int TH_, int TW_, int WC_, int FC_, int FP_, int NP_, bool F16_ = false>
 struct XCfg {
   static constexpr int MODE = MODE_, S = S_, NB = NB_, TH = TH_, TW = TW_, WC = WC_, WP = 4 / WC_, FC = FC_, FP = FP_;
   static constexpr int NP = NP_;
+  static constexpr bool F16 = F16_;       // fp16 planes (NP = 2): common.hpp, "split arithmetics"
+  static_assert(!F16_ || NP_ == 2, "fp16 planes: hi + lo");
   static constexpr int TN = 32 * WC * FC, TM = NB * TH * TW;
   static constexpr int NTMAX = (MODE == X_FWD) ? 5 : (5 + S - 1) / S;
   static constexpr int PH = (MODE == X_FWD) ? S * (TH - 1) + 5 : TH + NTMAX - 1;
@@ -78,11 +79,9 @@ struct XArgs {
   int ntiles_n, tiles_w, tiles_hw, blocks_per_cls;
   int ksplit, cps;       // forward only: grid-level split of the channel chunks (deep-K, small-grid layers)
   size_t ysplit;         // elements per partial output slab (then y points at the slabs)
+  const float* in_amax;  // fp16 planes: in_amax[0] >= max |x| (device); w_unscale[0]: the pack's trailer
+  const float* w_unscale;
 };
-
-__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
 
 // taps of the output-parity classes before (R, SS) (same order as conv_igemm.hip)
 __host__ __device__ constexpr int x_taps_before(int S, int R, int SS) {
@@ -100,6 +99,7 @@ __device__ __forceinline__ void bf16split_body(const XArgs& A, f32x4* lds, int b
   constexpr int MODE = C::MODE, S = C::S, NB = C::NB, TH = C::TH, TW = C::TW, PH = C::PH, PW = C::PW;
   constexpr int COLS = C::COLS, ROWU = C::ROWU, IMGU = C::IMGU, NQ = C::NQ, FC = C::FC, FP = C::FP, NP = C::NP;
   constexpr int NTMAX = C::NTMAX;
+  constexpr bool F16 = C::F16;
   constexpr int NTH = (MODE == X_FWD) ? 5 : (5 - R + S - 1) / S;   // taps along h / w in this class
   constexpr int NTW = (MODE == X_FWD) ? 5 : (5 - SS + S - 1) / S;
   constexpr int NTAP = NTH * NTW;
@@ -150,6 +150,12 @@ __device__ __forceinline__ void bf16split_body(const XArgs& A, f32x4* lds, int b
   }
   static_assert(NQ <= 32, "validity mask");
 
+  float x_scale = 1.f, x_unscale = 1.f;     // fp16 planes: exact power of two from the caller's bound on max |x|
+  if constexpr (F16) {
+    const float amax = *A.in_amax;
+    x_scale = f16_scale_of(amax);
+    x_unscale = f16_unscale_of(amax);
+  }
   float preg[NQ][8];
   auto load_chunk = [&](int c0) {
 #pragma unroll
@@ -161,20 +167,17 @@ __device__ __forceinline__ void bf16split_body(const XArgs& A, f32x4* lds, int b
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const bool ok = (pvalid >> q) & 1u;
-      bf16x8 pl[NP];
+      f32x4 pl[NP];
+      float vv[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float v = ok ? preg[q][j] : 0.f;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {          // hi, (mid,) lo: each plane takes the leading 8 bits of what is left
-          const __bf16 h = (__bf16)v;
-          pl[p][j] = h;
-          v -= (float)h;
-        }
+        const float v = ok ? preg[q][j] : 0.f;
+        vv[j] = F16 ? v * x_scale : v;
       }
+      split_planes16<NP, F16>(vv, pl);
       if (pdst[q] >= 0) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) lds[pdst[q] + p * 2 * IMGU] = __builtin_bit_cast(f32x4, pl[p]);
+        for (int p = 0; p < NP; ++p) lds[pdst[q] + p * 2 * IMGU] = pl[p];
       }
     }
   };
@@ -263,7 +266,7 @@ __device__ __forceinline__ void bf16split_body(const XArgs& A, f32x4* lds, int b
 #pragma unroll
             for (int g = 0; g < FC; ++g)
 #pragma unroll
-              for (int f = 0; f < FP; ++f) acc[g][f] = mfma_bf16(av[cur][g][pa], bv[BPF ? cur : 0][f][sum - pa], acc[g][f]);
+              for (int f = 0; f < FP; ++f) acc[g][f] = mfma_split16<F16>(av[cur][g][pa], bv[BPF ? cur : 0][f][sum - pa], acc[g][f]);
         if (PIN) __builtin_amdgcn_sched_barrier(0);
       }
       if (NTW & 1) {
@@ -280,6 +283,15 @@ __device__ __forceinline__ void bf16split_body(const XArgs& A, f32x4* lds, int b
     }
   }
 
+  if constexpr (F16) {   // undo the two operands' power-of-two scales (two exact multiplications)
+    const float w_unscale = *A.w_unscale;
+#pragma unroll
+    for (int g = 0; g < FC; ++g)
+#pragma unroll
+      for (int f = 0; f < FP; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][f][r] = acc[g][f][r] * x_unscale * w_unscale;
+  }
   // ---- epilogue: + bias, NCHW store (as conv_igemm.hip)
   const int YH = A.YH, YW = A.YW;
 #pragma unroll
@@ -330,6 +342,7 @@ __global__ __launch_bounds__(XNT, 2) void conv5x5_bf16split_kernel(XArgs A) {
 struct XSplit {
   int k;          // 1: no split
   float* slabs;   // k partial outputs
+  const float* in_amax;   // fp16 planes only
 };
 
 template <class C>
@@ -358,6 +371,8 @@ int launch_x(const float* x, const bf16x8* w, const float* bias, float* y, int B
   A.cps = cdiv(Cin / 16, ksplit);
   A.ysplit = (size_t)B * Cout * A.YH * A.YW;
   if (ksplit > 1) A.y = xs.slabs;
+  A.in_amax = xs.in_amax;
+  A.w_unscale = (const float*)(w + (size_t)(Cin / 16 * 25 + VG_PACK_SPARE) * 2 * C::NP * A.CoutP);      // the pack's trailer
   hipLaunchKernelGGL(conv5x5_bf16split_kernel<C>, dim3((unsigned)grid), dim3(XNT), 0, st, A);
   VG_CHECK_LAUNCH();
   if (ksplit > 1) {
@@ -369,29 +384,29 @@ int launch_x(const float* x, const bf16x8* w, const float* bias, float* y, int B
 
 VG_KNOB(int, g_x_tile_override, -1);   // diagnostics: 0 = 128 cout x 128 px, 1 = 64 x 128, 2 = 64 x 64, 3 = 32 cout x 128 px, 4 = 32 x 256 (transposed)
 
-template <int MODE, int S, int WC, int FC, int FP, int NP>
+template <int MODE, int S, int WC, int FC, int FP, int NP, bool F16>
 int dispatch_geom(const float* x, const bf16x8* w, const float* bias, float* y, int B, int Cin, int XH, int XW,
                   int Cout, XSplit xs, hipStream_t st) {
   const int tsw = (MODE == X_FWD) ? (XW - 1) / S + 1 : XW;
   constexpr int TM = 32 * (4 / WC) * FP;
   if constexpr (TM == 128) {
-    if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 4, 32, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
-    if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 8, 16, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
-    return launch_x<XCfg<MODE, S, 2, 8, 8, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+    if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 4, 32, WC, FC, FP, NP, F16>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+    if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 8, 16, WC, FC, FP, NP, F16>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+    return launch_x<XCfg<MODE, S, 2, 8, 8, WC, FC, FP, NP, F16>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
   } else if constexpr (TM == 256) {
-    if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 8, 32, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
-    if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 16, 16, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
-    return launch_x<XCfg<MODE, S, 4, 8, 8, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+    if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 8, 32, WC, FC, FP, NP, F16>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+    if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 16, 16, WC, FC, FP, NP, F16>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+    return launch_x<XCfg<MODE, S, 4, 8, 8, WC, FC, FP, NP, F16>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
   } else {
-    if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 2, 32, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
-    if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 4, 16, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
-    return launch_x<XCfg<MODE, S, 1, 8, 8, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+    if (tsw >= 32) return launch_x<XCfg<MODE, S, 1, 2, 32, WC, FC, FP, NP, F16>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+    if (tsw >= 16) return launch_x<XCfg<MODE, S, 1, 4, 16, WC, FC, FP, NP, F16>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+    return launch_x<XCfg<MODE, S, 1, 8, 8, WC, FC, FP, NP, F16>>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
   }
 }
 
 // Biggest tile that still gives every CU two workgroups (256 CUs): 128 cout x 128 px, else 64 cout x
 // 128 px, else 64 x 64; 32 cout x 128 px (4 wavefronts along the pixels) for thin outputs.
-template <int MODE, int S, int NP>
+template <int MODE, int S, int NP, bool F16 = false>
 int dispatch_x(const float* x, const bf16x8* w, const float* bias, float* y, int B, int Cin, int XH, int XW, int Cout,
                XSplit xs, hipStream_t st) {
   const int tsw = (MODE == X_FWD) ? (XW - 1) / S + 1 : XW, tsh = (MODE == X_FWD) ? (XH - 1) / S + 1 : XH;
@@ -407,14 +422,14 @@ int dispatch_x(const float* x, const bf16x8* w, const float* bias, float* y, int
   if (MODE == X_FWD && xs.k > 1) var = 0;             // split-K is sized for the 128 x 128 tile
   else if (g_x_tile_override >= 0 && g_x_tile_override <= 5 && !(g_x_tile_override == 4 && MODE == X_FWD))
     var = g_x_tile_override;
-  if (var == 0) return dispatch_geom<MODE, S, 2, 2, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
-  if (var == 1) return dispatch_geom<MODE, S, 2, 1, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
-  if (var == 3) return dispatch_geom<MODE, S, 1, 1, 1, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
-  if (var == 5) return dispatch_geom<MODE, S, 4, 1, 4, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);   // 4 wavefronts along cout
+  if (var == 0) return dispatch_geom<MODE, S, 2, 2, 2, NP, F16>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+  if (var == 1) return dispatch_geom<MODE, S, 2, 1, 2, NP, F16>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+  if (var == 3) return dispatch_geom<MODE, S, 1, 1, 1, NP, F16>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+  if (var == 5) return dispatch_geom<MODE, S, 4, 1, 4, NP, F16>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);   // 4 wavefronts along cout
   if constexpr (MODE == X_TR) {
-    if (var == 4) return dispatch_geom<MODE, S, 1, 1, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+    if (var == 4) return dispatch_geom<MODE, S, 1, 1, 2, NP, F16>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
   }
-  return dispatch_geom<MODE, S, 2, 1, 1, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
+  return dispatch_geom<MODE, S, 2, 1, 1, NP, F16>(x, w, bias, y, B, Cin, XH, XW, Cout, xs, st);
 }
 
 // packed[class][chunk][step][plane][k-block][CoutP] x 8 bf16 (+ VG_PACK_SPARE zero steps at the end: the ring
@@ -425,17 +440,23 @@ int dispatch_x(const float* x, const bf16x8* w, const float* bias, float* y, int
 //                   of channels 0-7, step 12 tap 24 of channels 0-7 | 8-15, steps 13-24 taps of channels 8-15;
 //   transposed = 1: w is [Cin][Cout][5][5], S*S parity classes, tap (a, b) of class (R, SS) is
 //                   (kh, kw) = (R + S*a, SS + S*b).
-constexpr int VG_PACK_SPARE = 3;
 constexpr int PK_CO = 8, PK_PITCH = 401;         // channels per workgroup (512 workgroups for a 256 x 256 filter: with 32
                                                  // channels and 128 workgroups it ran 21 us); floats per channel in LDS (400 + 1)
 // One workgroup = PK_CO output channels x one 16-channel chunk: the PK_CO x 16 x 25 filter values are read with contiguous
 // loads into LDS (400 contiguous floats per channel, or 800 per input channel for the transposed layout) and every
 // (channel, step, k-block) unit is built from there.  (The first version read each value with its own 4-byte load, a
 // lane's 16 values 100 bytes apart and the lanes 12.8 KB apart: 12.7 us for the 6.5 MB filter, 0.29 ms per iteration.)
+// planes & VG_PLANES_F16_FLAG: fp16 planes -- the filter is multiplied by f16_scale_of(w_amax[0]) first and the inverse of
+// that power of two is left in the pack's trailer (one float behind the spare steps) for the convolution's epilogue.
 __device__ __forceinline__ void pack_bf16split_body(float* T, const float* __restrict__ w, bf16x8* __restrict__ p,
                                                     int Cout, int Cin, int CoutP, int nsteps, int transposed, int S,
-                                                    int planes, int bx, int by) {
+                                                    int planes, const float* __restrict__ w_amax, int bx, int by) {
   const int tid = threadIdx.x;
+  const bool f16 = (planes & VG_PLANES_F16_FLAG) != 0;
+  planes &= 0xff;
+  const float wscale = f16 ? f16_scale_of(*w_amax) : 1.f;
+  if (f16 && bx == 0 && by == 0 && tid == 0)
+    *(float*)(p + (size_t)(nsteps + VG_PACK_SPARE) * planes * 2 * CoutP) = f16_unscale_of(*w_amax);
   const int co0 = bx * PK_CO, c16 = by, nchunks = Cin / 16;
   if (!transposed) {
     for (int e0 = tid; e0 < PK_CO * 400; e0 += 4 * 256) {
@@ -491,7 +512,16 @@ __device__ __forceinline__ void pack_bf16split_body(float* T, const float* __res
     }
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = T[col * PK_PITCH + (half * 8 + j) * 25 + tap];
+    for (int j = 0; j < 8; ++j) v[j] = T[col * PK_PITCH + (half * 8 + j) * 25 + tap] * wscale;
+    if (f16) {
+      f32x4 q2[2];
+      split_planes16<2, true>(v, q2);
+      if (cok) {
+        p[((size_t)step * 4 + kb) * CoutP + co0 + col] = __builtin_bit_cast(bf16x8, q2[0]);
+        p[((size_t)step * 4 + 2 + kb) * CoutP + co0 + col] = __builtin_bit_cast(bf16x8, q2[1]);
+      }
+      continue;
+    }
     for (int pl = 0; pl < planes; ++pl) {       // hi, (mid,) lo
       bf16x8 qv;
 #pragma unroll
@@ -514,9 +544,9 @@ __device__ __forceinline__ void pack_bf16split_body(float* T, const float* __res
 
 __global__ __launch_bounds__(256) void pack_bf16split_kernel(const float* __restrict__ w, bf16x8* __restrict__ p,
                                                          int Cout, int Cin, int CoutP, int nsteps, int transposed,
-                                                         int S, int planes) {
+                                                         int S, int planes, const float* __restrict__ w_amax) {
   __shared__ float T[PK_CO * PK_PITCH];          // [channel][ci16 * 25 + tap]
-  pack_bf16split_body(T, w, p, Cout, Cin, CoutP, nsteps, transposed, S, planes, blockIdx.x, blockIdx.y);
+  pack_bf16split_body(T, w, p, Cout, Cin, CoutP, nsteps, transposed, S, planes, w_amax, blockIdx.x, blockIdx.y);
 }
 
 // Several filters in ONE launch (every filter an optimizer step has just changed): a pack is latency-bound (8 us for
@@ -524,6 +554,7 @@ __global__ __launch_bounds__(256) void pack_bf16split_kernel(const float* __rest
 constexpr int PK_MAXE = 24;
 struct PackBatch {
   const float* w[PK_MAXE];
+  const float* w_amax[PK_MAXE];
   bf16x8* p[PK_MAXE];
   int Cout[PK_MAXE], Cin[PK_MAXE], transposed[PK_MAXE], S[PK_MAXE];
   unsigned first_block[PK_MAXE + 1];
@@ -537,7 +568,7 @@ __global__ __launch_bounds__(256) void pack_bf16split_multi_kernel(PackBatch P, 
   const int CoutP = (P.Cout[t] + 127) & ~127, nbx = CoutP / PK_CO;
   const int b = blockIdx.x - P.first_block[t];
   pack_bf16split_body(T, P.w[t], P.p[t], P.Cout[t], P.Cin[t], CoutP, P.Cin[t] / 16 * 25, P.transposed[t], P.S[t], planes,
-                      b % nbx, b / nbx);
+                      P.w_amax[t], b % nbx, b / nbx);
 }
 
 // Forward, deep K on a small grid (the 8 x 8-pixel layers): the 128 x 128 tile with the channel chunks split
@@ -552,10 +583,13 @@ int fwd_ksplit(int B, int Cin, int H, int W, int Cout, int S) {
   return k;
 }
 
+// 2 / 3 bf16 planes, or 2 fp16 planes (VG_PLANES_F16 | 2)
+int planes_ok(int planes) { return planes == 2 || planes == 3 || planes == (VG_PLANES_F16_FLAG | 2); }
+
 int x_args_ok(const float* x, const void* packed, float* y, int B, int Cin, int H, int W, int Cout, int stride,
               int planes) {
   if (!x || !packed || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
-  return (stride == 1 || stride == 2) && Cin % 16 == 0 && ((uintptr_t)packed & 15) == 0 && (planes == 2 || planes == 3);
+  return (stride == 1 || stride == 2) && Cin % 16 == 0 && ((uintptr_t)packed & 15) == 0 && planes_ok(planes);
 }
 
 }  // namespace
@@ -573,23 +607,27 @@ extern "C" int vg_debug_set_conv_ring_tile(int variant) {
 #endif
 
 extern "C" size_t vg_conv5x5_packed_bf16split_bytes(int Cout, int Cin, int planes) {
-  if (Cout <= 0 || Cin <= 0 || Cin % 16 || (planes != 2 && planes != 3)) return 0;
-  return (size_t)(Cin / 16 * 25 + VG_PACK_SPARE) * 2 * planes * ((Cout + 127) & ~127) * 16;
+  if (Cout <= 0 || Cin <= 0 || Cin % 16 || !planes_ok(planes)) return 0;
+  // fp16 planes: + a 16-byte trailer holding the inverse of the filter's power-of-two scale
+  return (size_t)(Cin / 16 * 25 + VG_PACK_SPARE) * 2 * (planes & 0xff) * ((Cout + 127) & ~127) * 16 +
+         ((planes & VG_PLANES_F16_FLAG) ? 16 : 0);
 }
 
 extern "C" int vg_conv5x5_pack_bf16split(const float* w, void* packed, int Cout, int Cin, int transposed, int stride,
-                                      int planes, void* stream) {
+                                      int planes, const float* w_amax, void* stream) {
   if (!w || !packed || Cout <= 0 || Cin <= 0 || Cin % 16 || ((uintptr_t)packed & 15)) return VG_ERR_BAD_ARG;
-  if ((stride != 1 && stride != 2) || (planes != 2 && planes != 3)) return VG_ERR_BAD_ARG;
+  if ((stride != 1 && stride != 2) || !planes_ok(planes)) return VG_ERR_BAD_ARG;
+  if ((planes & VG_PLANES_F16_FLAG) && !w_amax) return VG_ERR_BAD_ARG;
   const int CoutP = (Cout + 127) & ~127, nsteps = Cin / 16 * 25;
   hipLaunchKernelGGL(pack_bf16split_kernel, dim3(CoutP / PK_CO, Cin / 16), dim3(256), 0,
-                     (hipStream_t)stream, w, (bf16x8*)packed, Cout, Cin, CoutP, nsteps, transposed ? 1 : 0, stride, planes);
+                     (hipStream_t)stream, w, (bf16x8*)packed, Cout, Cin, CoutP, nsteps, transposed ? 1 : 0, stride, planes,
+                     w_amax);
   VG_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int vg_conv5x5_pack_bf16split_multi(const VgPackEntry* entries, int count, int planes, void* stream) {
-  if (count < 0 || (count > 0 && !entries) || (planes != 2 && planes != 3)) return VG_ERR_BAD_ARG;
+  if (count < 0 || (count > 0 && !entries) || !planes_ok(planes)) return VG_ERR_BAD_ARG;
   int i = 0;
   while (i < count) {
     PackBatch P;
@@ -598,9 +636,10 @@ extern "C" int vg_conv5x5_pack_bf16split_multi(const VgPackEntry* entries, int c
     while (i < count && P.count < PK_MAXE) {
       const VgPackEntry& E = entries[i++];
       if (!E.w || !E.packed || E.Cout <= 0 || E.Cin <= 0 || E.Cin % 16 || ((uintptr_t)E.packed & 15) ||
-          (E.stride != 1 && E.stride != 2))
+          (E.stride != 1 && E.stride != 2) || ((planes & VG_PLANES_F16_FLAG) && !E.w_amax))
         return VG_ERR_BAD_ARG;
       const int k = P.count++;
+      P.w_amax[k] = E.w_amax;
       P.w[k] = E.w; P.p[k] = (bf16x8*)E.packed; P.Cout[k] = E.Cout; P.Cin[k] = E.Cin;
       P.transposed[k] = E.transposed ? 1 : 0; P.S[k] = E.stride;
       P.first_block[k] = blocks;
@@ -625,7 +664,7 @@ extern "C" size_t vg_conv5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H
   return (size_t)k * B * Cout * ((H - 1) / stride + 1) * ((W - 1) / stride + 1) * sizeof(float);
 }
 
-static bool fuse_empty(const vg_conv_fusion* f) { return !f || (!f->in_scale && !f->in_shift && !f->stats); }
+static bool fuse_empty(const vg_conv_fusion* f) { return !f || (!f->in_scale && !f->in_shift && !f->stats); }   // in_amax is not a fusion
 
 extern "C" int vg_conv5x5_bf16split_fusable(int transposed, int Cin, int Cout, int stride) {
   if (Cin <= 0 || Cin % 16 || Cout <= 0) return 0;
@@ -650,13 +689,17 @@ extern "C" int vg_conv5x5_fwd_bf16split(const float* x, const void* packed, cons
   if (stride == 2)
     return vg_internal_ring_conv(0, x, packed, bias, y, B, Cin, H, W, Cout, planes, workspace, workspace_bytes,
                                  fuse ? fuse->in_scale : nullptr, fuse ? fuse->in_shift : nullptr, fuse ? fuse->in_act : 0,
-                                 fuse ? fuse->stats : nullptr, fuse ? fuse->stats_floats : 0, st);
+                                 fuse ? fuse->stats : nullptr, fuse ? fuse->stats_floats : 0, fuse ? fuse->in_amax : nullptr, st);
   if (!fuse_empty(fuse)) return VG_ERR_BAD_ARG;        // vg_conv5x5_bf16split_fusable says which layers take it
   const bf16x8* w = (const bf16x8*)packed;
   const int k = fwd_ksplit(B, Cin, H, W, Cout, stride);
   if (k > 1 && (!workspace || workspace_bytes < vg_conv5x5_fwd_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride)))
     return VG_ERR_WORKSPACE;
-  const XSplit xs = {k, (float*)workspace};
+  const XSplit xs = {k, (float*)workspace, fuse ? fuse->in_amax : nullptr};
+  if (planes & VG_PLANES_F16_FLAG) {
+    if (!xs.in_amax) return VG_ERR_BAD_ARG;
+    return dispatch_x<X_FWD, 1, 2, true>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
+  }
   if (planes == 2) return dispatch_x<X_FWD, 1, 2>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
   return dispatch_x<X_FWD, 1, 3>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
 }
@@ -674,13 +717,19 @@ extern "C" int vg_convT5x5_fwd_bf16split(const float* x, const void* packed, con
   if (tr_on_ring(Cout, stride))
     return vg_internal_ring_conv(1, x, packed, bias, y, B, Cin, H, W, Cout, planes, workspace, workspace_bytes,
                                  fuse ? fuse->in_scale : nullptr, fuse ? fuse->in_shift : nullptr, fuse ? fuse->in_act : 0,
-                                 fuse ? fuse->stats : nullptr, fuse ? fuse->stats_floats : 0, st);
+                                 fuse ? fuse->stats : nullptr, fuse ? fuse->stats_floats : 0, fuse ? fuse->in_amax : nullptr, st);
   if (!fuse_empty(fuse)) return VG_ERR_BAD_ARG;
   const bf16x8* w = (const bf16x8*)packed;
-  if (planes == 2) {
-    if (stride == 2) return dispatch_x<X_TR, 2, 2>(x, w, bias, y, B, Cin, H, W, Cout, XSplit{1, nullptr}, st);
-    return dispatch_x<X_TR, 1, 2>(x, w, bias, y, B, Cin, H, W, Cout, XSplit{1, nullptr}, st);
+  const XSplit xs = {1, nullptr, fuse ? fuse->in_amax : nullptr};
+  if (planes & VG_PLANES_F16_FLAG) {
+    if (!xs.in_amax) return VG_ERR_BAD_ARG;
+    if (stride == 2) return dispatch_x<X_TR, 2, 2, true>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
+    return dispatch_x<X_TR, 1, 2, true>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
   }
-  if (stride == 2) return dispatch_x<X_TR, 2, 3>(x, w, bias, y, B, Cin, H, W, Cout, XSplit{1, nullptr}, st);
-  return dispatch_x<X_TR, 1, 3>(x, w, bias, y, B, Cin, H, W, Cout, XSplit{1, nullptr}, st);
+  if (planes == 2) {
+    if (stride == 2) return dispatch_x<X_TR, 2, 2>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
+    return dispatch_x<X_TR, 1, 2>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
+  }
+  if (stride == 2) return dispatch_x<X_TR, 2, 3>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
+  return dispatch_x<X_TR, 1, 3>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
 }

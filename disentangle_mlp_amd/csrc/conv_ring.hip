@@ -25,8 +25,6 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-
 enum { R_FWD = 0, R_TR = 1 };
 constexpr int RNT = 512;          // 8 wavefronts
 constexpr int NSLOT = 3;
@@ -44,9 +42,11 @@ constexpr int ring_cols(int mode, int TW, int PW) {
   return (PW + 3) & ~3;
 }
 
-template <int MODE_, int NB_, int TH_, int TW_, int WC_, int FC_, int FP_, int NP_>
+template <int MODE_, int NB_, int TH_, int TW_, int WC_, int FC_, int FP_, int NP_, bool F16_ = false>
 struct RCfg {
   static constexpr int MODE = MODE_, NB = NB_, TH = TH_, TW = TW_, WC = WC_, WP = 8 / WC_, FC = FC_, FP = FP_, NP = NP_;
+  static constexpr bool F16 = F16_;       // fp16 planes (NP = 2, "fp16x3") instead of bf16 ones
+  static_assert(!F16_ || NP_ == 2, "fp16 planes: hi + lo");
   static constexpr int S = 2;
   static constexpr int TN = 32 * WC * FC, TM = NB * TH * TW;
   static constexpr int NTMAX = (MODE == R_FWD) ? 5 : 3;
@@ -92,11 +92,11 @@ struct RArgs {
   const float* in_shift;
   int in_act;
   float* stats;        // [slot][Cout][2]
+  // fp16 planes: in_amax[0] >= max |activated input| (device); w_unscale[0] = the inverse of the power of two the pack
+  // kernel multiplied the filter by (stored behind the pack).  NULL for bf16 planes.
+  const float* in_amax;
+  const float* w_unscale;
 };
-
-__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
 
 // steps (of 16 k) of the transposed classes before (R, SS), per chunk of 16 channels
 __host__ __device__ constexpr int tr_taps_before(int R, int SS) {
@@ -122,6 +122,7 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
   constexpr int MODE = C::MODE, S = C::S, NB = C::NB, TH = C::TH, TW = C::TW, PH = C::PH, PW = C::PW;
   constexpr int COLS = C::COLS, ROWU = C::ROWU, IMGU = C::IMGU, NQ = C::NQ, FC = C::FC, FP = C::FP, NP = C::NP;
   constexpr int NTMAX = C::NTMAX, BUFU = C::BUFU, SLOTU = C::SLOTU, NDMA = C::NDMA, NL = C::NL, TN = C::TN;
+  constexpr bool F16 = C::F16;
   constexpr int NTH = (MODE == R_FWD) ? 5 : (5 - R + 1) / 2;     // taps along h / w in this class
   constexpr int NTW = (MODE == R_FWD) ? 5 : (5 - SS + 1) / 2;
   constexpr int NSTEP = NTH * NTW;                                // K steps per 16-channel chunk (FWD: 25)
@@ -207,6 +208,13 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
   const float* aff_scale = A.in_scale ? A.in_scale : &k_unit_scale;
   const float* aff_shift = A.in_scale ? A.in_shift : &k_zero_shift;
   const float aff_slope = !A.in_scale || A.in_act == VG_ACT_NONE ? 1.f : (A.in_act == VG_ACT_RELU ? 0.f : 0.2f);
+  // fp16 planes: the activated input times an exact power of two (wave-uniform, from the caller's bound on max |input|)
+  float x_scale = 1.f, x_unscale = 1.f;
+  if constexpr (F16) {
+    const float amax = *A.in_amax;
+    x_scale = f16_scale_of(amax);
+    x_unscale = f16_unscale_of(amax);
+  }
   // c0 = first channel of the 8 (FWD) / 16 (TR) channels to stage; clamped so that the address stays in the tensor
   // (past-the-end events happen at the last chunk and are never consumed)
   auto stage_load = [&](int c0) {
@@ -224,7 +232,8 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
   };
   auto split_unit = [&](int q, int bufu) {          // fp32 -> planes of staged unit q, written to buffer `bufu`
     const Unit u = unit_of(q);
-    bf16x8 pl[NP];
+    f32x4 pl[NP];
+    float vv[8];
     // BatchNorm + activation of the producing layer, on load -- branch-free (a branch here keeps hipcc from unrolling
     // the K steps, and the fragment registers then go to scratch): without a fusion the coefficients are 1 / 0 /
     // slope 1 read from element 0 of constant arrays.  Scalar loads: a unit's channels are wave-uniform.
@@ -232,19 +241,15 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = fmaf(preg[q][j], aff_scale[cb + (aff_mask & j)], aff_shift[cb + (aff_mask & j)]);
-      v = fmaxf(v, 0.f) + aff_slope * fminf(v, 0.f);  // slope 1: identity, 0: ReLU, 0.2: LeakyReLU
+      v = act_slope(v, aff_slope);                    // slope 1: identity, 0: ReLU, 0.2: LeakyReLU
       v = u.ok ? v : 0.f;                             // zero padding pads the ACTIVATED tensor
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {                // hi, (mid,) lo: each plane takes the leading 8 bits of what is left
-        const __bf16 h = (__bf16)v;
-        pl[p][j] = h;
-        v -= (float)h;
-      }
+      vv[j] = F16 ? v * x_scale : v;
     }
+    split_planes16<NP, F16>(vv, pl);
     const int d = PATCH0 + bufu + u.dst;            // masked units go to the dummy unit (no divergent branch)
 #pragma unroll
     for (int p = 0; p < NP; ++p)
-      lds[(u.dst >= 0) ? d + p * ((MODE == R_FWD) ? IMGU : 2 * IMGU) : DUMMY] = __builtin_bit_cast(f32x4, pl[p]);
+      lds[(u.dst >= 0) ? d + p * ((MODE == R_FWD) ? IMGU : 2 * IMGU) : DUMMY] = pl[p];
   };
   auto stage_store = [&](int bufu) {
 #pragma unroll
@@ -351,7 +356,7 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
 #pragma unroll
       for (int r = 0; r < 4; ++r) { acc[g][f][r] = c0[r]; acc[g][f][4 + r] = c1[r]; }
     } else {
-      acc[g][f] = mfma_bf16(av[buf][g][pa], bv[buf][f][pb], acc[g][f]);
+      acc[g][f] = mfma_split16<F16>(av[buf][g][pa], bv[buf][f][pb], acc[g][f]);
     }
   };
   // a step's MFMAs with the next step's fragment reads spread between them (one read per RS MFMAs), pinned
@@ -492,6 +497,15 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
     }
   }
   wait_vmcnt<0>();     // nothing of the ring is in flight when the workgroup ends
+  if constexpr (F16) {   // undo the two operands' power-of-two scales (two exact multiplications: no intermediate overflow)
+    const float w_unscale = *A.w_unscale;
+#pragma unroll
+    for (int g = 0; g < FC; ++g)
+#pragma unroll
+      for (int f = 0; f < FP; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][f][r] = acc[g][f][r] * x_unscale * w_unscale;
+  }
 
   const int YH = A.YH, YW = A.YW;
   // ---- optional: per-channel sums of the output for the next BatchNorm (ksplit == 1 only: the host says so)
@@ -588,6 +602,7 @@ struct RFuse {
   const float* in_shift;
   int in_act;
   float* stats;
+  const float* in_amax;
 };
 
 template <class C>
@@ -597,6 +612,9 @@ int launch_ring(const float* x, const bf16x8* w, const float* bias, float* y, in
   A.x = x; A.w = w; A.bias = bias; A.y = y;
   A.in_scale = fu.in_scale; A.in_shift = fu.in_shift; A.in_act = fu.in_act;
   A.stats = (ksplit == 1) ? fu.stats : nullptr;
+  A.in_amax = fu.in_amax;
+  // the pack's trailer (conv_bf16split.hip, pack kernel): behind the steps and the spare steps
+  A.w_unscale = (const float*)(w + (size_t)(Cin / 16 * 25 + 3) * 2 * C::NP * ((Cout + 127) & ~127));
   A.B = B; A.Cin = Cin; A.XH = XH; A.XW = XW; A.Cout = Cout; A.CoutP = (Cout + 127) & ~127;
   int tsh, tsw;
   if (C::MODE == R_FWD) {
@@ -626,20 +644,20 @@ int launch_ring(const float* x, const bf16x8* w, const float* bias, float* y, in
 }
 
 // pixel-tile geometry by the width of the tiled image (forward: output, transposed: input)
-template <int MODE, int WC, int FC, int FP, int NP>
+template <int MODE, int WC, int FC, int FP, int NP, bool F16>
 int ring_geom(const float* x, const bf16x8* w, const float* bias, float* y, int B, int Cin, int XH, int XW, int Cout,
               int ksplit, float* slabs, RFuse fu, hipStream_t st) {
   const int tsw = (MODE == R_FWD) ? (XW - 1) / 2 + 1 : XW;
   constexpr int TM = 32 * (8 / WC) * FP;
   static_assert(TM == 128 || TM == 256, "pixel tile");
   if constexpr (TM == 128) {
-    if (tsw > 8) return launch_ring<RCfg<MODE, 1, 8, 16, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
+    if (tsw > 8) return launch_ring<RCfg<MODE, 1, 8, 16, WC, FC, FP, NP, F16>>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
     // transposed, 8-wide images, 256 cout: ring + the two 2 x 10 x 10 patches (24 units per row) exceed the LDS;
     // the plan sends those layers to the 128-cout tiles
     if constexpr (MODE == R_TR && WC * FC * 32 == 256) return VG_ERR_BAD_ARG;
-    else return launch_ring<RCfg<MODE, 2, 8, 8, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
+    else return launch_ring<RCfg<MODE, 2, 8, 8, WC, FC, FP, NP, F16>>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
   } else {   // 256 pixels: whole 16 x 16 tiles only (the plan never picks it for narrower images)
-    return launch_ring<RCfg<MODE, 1, 16, 16, WC, FC, FP, NP>>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
+    return launch_ring<RCfg<MODE, 1, 16, 16, WC, FC, FP, NP, F16>>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
   }
 }
 
@@ -650,15 +668,15 @@ VG_KNOB(int, g_ring_variant, -1);   // tuning build only: forced tile variant
 // Tile variants.  0: 256 cout x 128 px (4 x 2 wavefronts of 64 x 64); 1: 128 cout x 128 px (2 x 4 wavefronts of
 // 64 cout x 32 px); 2: 128 cout x 128 px (4 x 2 wavefronts of 32 cout x 64 px); 3 (transposed only, small patch):
 // 128 cout x 256 px (2 x 4 wavefronts of 64 x 64).
-template <int MODE, int NP>
+template <int MODE, int NP, bool F16>
 static int ring_dispatch(int variant, const float* x, const bf16x8* w, const float* bias, float* y, int B, int Cin, int XH,
                          int XW, int Cout, int ksplit, float* slabs, RFuse fu, hipStream_t st) {
   switch (variant) {
-    case 0: return ring_geom<MODE, 4, 2, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
-    case 1: return ring_geom<MODE, 2, 2, 1, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
-    case 2: return ring_geom<MODE, 4, 1, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
+    case 0: return ring_geom<MODE, 4, 2, 2, NP, F16>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
+    case 1: return ring_geom<MODE, 2, 2, 1, NP, F16>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
+    case 2: return ring_geom<MODE, 4, 1, 2, NP, F16>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
     default:
-      if constexpr (MODE == R_TR) return ring_geom<MODE, 2, 2, 2, NP>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
+      if constexpr (MODE == R_TR) return ring_geom<MODE, 2, 2, 2, NP, F16>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
       return VG_ERR_BAD_ARG;
   }
 }
@@ -718,21 +736,27 @@ size_t vg_internal_ring_stats_floats(int mode, int B, int Cin, int H, int W, int
 
 int vg_internal_ring_conv(int mode, const float* x, const void* packed, const float* bias, float* y, int B, int Cin, int H,
                           int W, int Cout, int planes, void* workspace, size_t workspace_bytes, const float* in_scale,
-                          const float* in_shift, int in_act, float* stats, size_t stats_floats, hipStream_t st) {
+                          const float* in_shift, int in_act, float* stats, size_t stats_floats, const float* in_amax,
+                          hipStream_t st) {
   const RingPlan p = ring_plan(mode, B, Cin, H, W, Cout);
   if (p.ksplit > 1 && (!workspace || workspace_bytes < vg_internal_ring_workspace_bytes(mode, B, Cin, H, W, Cout)))
     return VG_ERR_WORKSPACE;
   if ((in_scale == nullptr) != (in_shift == nullptr) || in_act < VG_ACT_NONE || in_act > VG_ACT_LRELU) return VG_ERR_BAD_ARG;
   if (stats && (p.ksplit > 1 || stats_floats < vg_internal_ring_stats_floats(mode, B, Cin, H, W, Cout))) return VG_ERR_BAD_ARG;
-  const RFuse fu = {in_scale, in_shift, in_act, stats};
+  const bool f16 = (planes & VG_PLANES_F16_FLAG) != 0;
+  planes &= 0xff;
+  if (f16 && (planes != 2 || !in_amax)) return VG_ERR_BAD_ARG;
+  const RFuse fu = {in_scale, in_shift, in_act, stats, in_amax};
   const bf16x8* w = (const bf16x8*)packed;
   float* slabs = (float*)workspace;
   if (mode == R_FWD) {
-    if (planes == 3) return ring_dispatch<R_FWD, 3>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, fu, st);
-    return ring_dispatch<R_FWD, 2>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, fu, st);
+    if (f16) return ring_dispatch<R_FWD, 2, true>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, fu, st);
+    if (planes == 3) return ring_dispatch<R_FWD, 3, false>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, fu, st);
+    return ring_dispatch<R_FWD, 2, false>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, fu, st);
   }
-  if (planes == 3) return ring_dispatch<R_TR, 3>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, fu, st);
-  return ring_dispatch<R_TR, 2>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, fu, st);
+  if (f16) return ring_dispatch<R_TR, 2, true>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, fu, st);
+  if (planes == 3) return ring_dispatch<R_TR, 3, false>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, fu, st);
+  return ring_dispatch<R_TR, 2, false>(p.variant, x, w, bias, y, B, Cin, H, W, Cout, p.ksplit, slabs, fu, st);
 }
 
 #ifdef VG_TUNING

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(512) void convT_s1_thin_mfma_kernel(TArgs A) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float t = fmaf(raw[slot][j], sc[j], sh[j]);                   // the producing layer's BatchNorm ...
-      t = fmaxf(t, 0.f) + A.in_slope * fminf(t, 0.f);               // ... and activation, on load
+      t = act_slope(t, A.in_slope);                                 // ... and activation, on load
       v[j] = ok ? t : 0.f;                                          // padding pads the activated tensor
     }
     split_frag<NP>(v, win[slot]);

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(WNT) void conv_thin_wgrad_kernel(TWArgs A) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float v = fmaf(raw[slot][m][j], a_sc[m], a_sh[m]);
-            raw[slot][m][j] = fmaxf(v, 0.f) + A.gy_slope * fminf(v, 0.f);
+            raw[slot][m][j] = act_slope(v, A.gy_slope);
           }
         }
         split_frag<NP>(raw[slot][m], af[m]);

@@ -29,8 +29,6 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-
 constexpr int WTW = 8, WCIT = 5;
 
 struct WXArgs {
@@ -46,34 +44,20 @@ struct WXArgs {
   int mtiles, ntiles, tiles_w, tiles_hw, chunks;
   int units, upw;                 // units = output tiles x chunks; every workgroup works off upw consecutive ones
   unsigned short order[256];      // launch slot (blockIdx.x) -> workgroup index
+  const float* x_amax;            // fp16 planes: x_amax[0] >= max |activated x| (device); the slab sum undoes the scales
 };
-
-__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
-// v[8] -> NP bf16x8 values, each plane the leading 8 mantissa bits of what is left
-template <int NP>
-__device__ __forceinline__ void split_planes(float* v, bf16x8* out) {
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const __bf16 h = (__bf16)v[j];
-      out[p][j] = h;
-      v[j] -= (float)h;
-    }
-  }
-}
 
 // ---- gy[B][Co][P] -> Gp[bg][p][plane][kb][CoP] x 8 images; 32 pixels x 32 channels per workgroup
 // optional g_scale / g_shift / g_slope: the operand is read as act(gy * scale[co] + shift[co]) (a fused BatchNorm: the
 // weight gradient of a TRANSPOSED convolution takes the layer's input here)
-template <int NP>
+// F16: fp16 planes of gy * f16_scale_of(g_amax[0]) (common.hpp, "split arithmetics")
+template <int NP, bool F16>
 __global__ __launch_bounds__(256) void relayout_gy_kernel(const float* __restrict__ gy, bf16x8* __restrict__ gp,
                                                          int B, int Co, int CoP, int P, const float* __restrict__ g_scale,
-                                                         const float* __restrict__ g_shift, float g_slope) {
+                                                         const float* __restrict__ g_shift, float g_slope,
+                                                         const float* __restrict__ g_amax) {
   __shared__ float tile[8][32][33];
+  const float gsc16 = F16 ? f16_scale_of(*g_amax) : 1.f;
   const int tid = threadIdx.x;
   const int p0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
   const int bg = blockIdx.z >> 1, kb = blockIdx.z & 1;
@@ -97,7 +81,7 @@ __global__ __launch_bounds__(256) void relayout_gy_kernel(const float* __restric
         float t = v[j][e];
         if (g_scale) {
           t = fmaf(t, sc, sh);
-          t = fmaxf(t, 0.f) + g_slope * fminf(t, 0.f);
+          t = act_slope(t, g_slope);
         }
         tile[j][tid >> 3][q4 + e] = ok ? t : 0.f;
       }
@@ -115,7 +99,7 @@ __global__ __launch_bounds__(256) void relayout_gy_kernel(const float* __restric
           v = gy[((size_t)b * Co + co) * P + p0 + pl];
           if (g_scale) {
             v = fmaf(v, g_scale[co], g_shift[co]);
-            v = fmaxf(v, 0.f) + g_slope * fminf(v, 0.f);
+            v = act_slope(v, g_slope);
           }
         }
         tile[j][r + 8 * rr][pl] = v;
@@ -130,12 +114,12 @@ __global__ __launch_bounds__(256) void relayout_gy_kernel(const float* __restric
     if (p0 + pp >= P) continue;
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = tile[j][cc][pp];
-    bf16x8 pl[NP];
-    split_planes<NP>(v, pl);
+    for (int j = 0; j < 8; ++j) v[j] = F16 ? tile[j][cc][pp] * gsc16 : tile[j][cc][pp];
+    f32x4 pl[NP];
+    split_planes16<NP, F16>(v, pl);
 #pragma unroll
     for (int p = 0; p < NP; ++p)
-      gp[((((size_t)bg * P + p0 + pp) * NP + p) * 2 + kb) * CoP + co0 + cc] = pl[p];
+      gp[((((size_t)bg * P + p0 + pp) * NP + p) * 2 + kb) * CoP + co0 + cc] = __builtin_bit_cast(bf16x8, pl[p]);
   }
 }
 
@@ -156,9 +140,10 @@ constexpr int W8NT = 512;
 #define VG_WX_ABL 0
 #endif
 
-template <int S_, int NP_, int WCO_, int TH_>
+template <int S_, int NP_, int WCO_, int TH_, bool F16_ = false>
 struct W8 {
   static constexpr int S = S_, NP = NP_, WCO = WCO_, WN = 8 / WCO_, FP = 4 / WN, TCO = 32 * WCO_;
+  static constexpr bool F16 = F16_;
   static constexpr int TH = TH_, NPIX = TH_ * WTW;                                // output pixels of a chunk: TH rows x 8
   // gy prefetch distance in pixels (register sets - 1): a pixel step is FP * 6 (or 3) MFMAs per wavefront, i.e. 0.35 /
   // 0.7 us, against ~2 us for a first touch of gy from HBM; the 2-fragment tile has the registers for 8 sets
@@ -183,7 +168,9 @@ template <class C>
 __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A) {
   constexpr int S = C::S, PH = C::PH, PW = C::PW, ROWU = C::ROWU, CIU = C::CIU, KBU = C::KBU, NQ = C::NQ;
   constexpr int NP = C::NP, FP = C::FP, BUFU = C::BUFU, PD = C::PD;
+  constexpr bool F16 = C::F16;
   __shared__ f32x4 lds[2 * BUFU];          // [buffer][plane][k-block][ci][row][col] x 8 images
+  const float x_scale = F16 ? f16_scale_of(*A.x_amax) : 1.f;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kb = lane >> 5, l32 = lane & 31;
@@ -257,15 +244,16 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float t = fmaf(preg[q][j], psc[q], psh[q]);                    // the producing layer's BatchNorm ...
-      t = fmaxf(t, 0.f) + A.in_slope * fminf(t, 0.f);                // ... and activation, on load
+      t = act_slope(t, A.in_slope);                                  // ... and activation, on load
+      t = F16 ? t * x_scale : t;
       v[j] = (live && (bgrp * 16 + kbs * 8 + j) < A.B) ? t : 0.f;    // padding pads the activated tensor
     }
-    bf16x8 pl[NP];
-    split_planes<NP>(v, pl);
+    f32x4 pl[NP];
+    split_planes16<NP, F16>(v, pl);
     const int dst = buf * BUFU + kbs * KBU + ((d >> 9) & 7) * CIU + (d & 15) * ROWU + ((d >> 4) & 31);
     if (d >> 13) {
 #pragma unroll
-      for (int p = 0; p < NP; ++p) lds[dst + p * 2 * KBU] = __builtin_bit_cast(f32x4, pl[p]);
+      for (int p = 0; p < NP; ++p) lds[dst + p * 2 * KBU] = pl[p];
     }
   };
   auto store_patch = [&](int buf, int chunk) {
@@ -381,7 +369,7 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
           for (int pa = sum; pa >= 0; --pa)
 #pragma unroll
             for (int f = 0; f < FP; ++f) {
-              if (!(VG_WX_ABL & 8)) acc[f] = mfma_bf16(av[t & PD][pa], bv[f][sum - pa], acc[f]);
+              if (!(VG_WX_ABL & 8)) acc[f] = mfma_split16<F16>(av[t & PD][pa], bv[f][sum - pa], acc[f]);
               else acc[f][0] += (float)av[t & PD][pa][0] + (float)bv[f][sum - pa][0];
             }
         // one unit of the next patch per slot of the store schedule (the other buffer was last read a chunk ago).
@@ -418,9 +406,12 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
 
 // dw[e] = sum of the pieces of e's output tile, in workgroup order (fixed: the result does not depend on timing)
 __global__ __launch_bounds__(256) void wx_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int Cin,
-                                                       int tco, int mtiles, int chunks, int upw, unsigned n, int accumulate) {
+                                                       int tco, int mtiles, int chunks, int upw, unsigned n, int accumulate,
+                                                       const float* __restrict__ x_amax, const float* __restrict__ gy_amax) {
   const unsigned e = blockIdx.x * 256u + threadIdx.x;
   if (e >= n) return;
+  // fp16 planes: the two operands' power-of-two scales are undone here, once per output (exact)
+  const float ux = x_amax ? f16_unscale_of(*x_amax) : 1.f, ug = gy_amax ? f16_unscale_of(*gy_amax) : 1.f;
   const int row = Cin * 25, co = e / row, ci = (e - co * row) / 25;
   const long tile = (long)(ci / WCIT) * mtiles + co / tco;
   const int first = (int)((tile * chunks) / upw), last = (int)(((tile + 1) * chunks - 1) / upw);
@@ -436,7 +427,7 @@ __global__ __launch_bounds__(256) void wx_reduce_kernel(const float* __restrict_
     for (int k = 0; k < 4; ++k) sum += v[k];
   }
   for (; p < cnt; ++p) sum += slabs[(size_t)p * n + e];
-  dw[e] = sum + (accumulate ? dw[e] : 0.f);        // accumulate: see wgrad_reduce_kernel
+  dw[e] = sum * ux * ug + (accumulate ? dw[e] : 0.f);        // accumulate: see wgrad_reduce_kernel
 }
 
 struct XPlan {
@@ -509,10 +500,10 @@ int launch_wx(const WXArgs& A, long grid, hipStream_t st) {
   return 0;
 }
 
-template <int S, int NP>
+template <int S, int NP, bool F16 = false>
 int launch_wx_by_cout(const WXArgs& A, int wco, int th, long grid, hipStream_t st) {
-  if (th == 2) return wco == 8 ? launch_wx<W8<S, NP, 8, 2>>(A, grid, st) : launch_wx<W8<S, NP, 4, 2>>(A, grid, st);
-  return wco == 8 ? launch_wx<W8<S, NP, 8, 1>>(A, grid, st) : launch_wx<W8<S, NP, 4, 1>>(A, grid, st);
+  if (th == 2) return wco == 8 ? launch_wx<W8<S, NP, 8, 2, F16>>(A, grid, st) : launch_wx<W8<S, NP, 4, 2, F16>>(A, grid, st);
+  return wco == 8 ? launch_wx<W8<S, NP, 8, 1, F16>>(A, grid, st) : launch_wx<W8<S, NP, 4, 1, F16>>(A, grid, st);
 }
 
 }  // namespace
@@ -524,17 +515,21 @@ void vg_internal_wx_set_th(int th) { g_wx_th = (th == 1 || th == 2) ? th : 0; }
 extern "C" size_t vg_conv5x5_wgrad_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride,
                                                           int planes) {
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return 0;
-  if (planes != 2 && planes != 3) return 0;
+  if (planes != 2 && planes != 3 && planes != (VG_PLANES_F16_FLAG | 2)) return 0;
   XPlan p;
-  if (!make_xplan(B, Cin, H, W, Cout, stride, planes, p)) return 0;     // 0: shape not supported by this mode
+  if (!make_xplan(B, Cin, H, W, Cout, stride, planes & 0xff, p)) return 0;     // 0: shape not supported by this mode
   return p.gp_bytes + p.slab_bytes;
 }
 
 extern "C" int vg_conv5x5_wgrad_bf16split(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W,
                                        int Cout, int stride, int planes, void* workspace, size_t workspace_bytes,
                                        const float* in_scale, const float* in_shift, int in_act, int affine_on_gy,
-                                       int accumulate, void* stream) {
+                                       const float* x_amax, const float* gy_amax, int accumulate, void* stream) {
   if (!x || !gy || !dw || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return VG_ERR_BAD_ARG;
+  const bool f16 = (planes & VG_PLANES_F16_FLAG) != 0;
+  planes &= 0xff;
+  if (f16 && (planes != 2 || !x_amax || !gy_amax)) return VG_ERR_BAD_ARG;
+  if (!f16) x_amax = gy_amax = nullptr;
   if ((in_scale == nullptr) != (in_shift == nullptr) || in_act < VG_ACT_NONE || in_act > VG_ACT_LRELU) return VG_ERR_BAD_ARG;
   const float slope = (!in_scale || in_act == VG_ACT_NONE) ? 1.f : (in_act == VG_ACT_RELU ? 0.f : 0.2f);
   const float* gsc = affine_on_gy ? in_scale : nullptr;      // coefficients per channel of gy (Cout of them) ...
@@ -551,11 +546,12 @@ extern "C" int vg_conv5x5_wgrad_bf16split(const float* x, const float* gy, float
   const int P = p.OH * p.OW;
   if ((size_t)Cin * H * W * 4 > 0xffffffffUL || p.BG * 2 > 65535 || p.CoP / 32 > 65535) return VG_ERR_BAD_ARG;
   const dim3 gg(cdiv(P, 32), p.CoP / 32, p.BG * 2);
-  if (planes == 2) hipLaunchKernelGGL(relayout_gy_kernel<2>, gg, dim3(256), 0, st, gy, gp, B, Cout, p.CoP, P, gsc, gsh, slope);
-  else hipLaunchKernelGGL(relayout_gy_kernel<3>, gg, dim3(256), 0, st, gy, gp, B, Cout, p.CoP, P, gsc, gsh, slope);
+  if (f16) hipLaunchKernelGGL((relayout_gy_kernel<2, true>), gg, dim3(256), 0, st, gy, gp, B, Cout, p.CoP, P, gsc, gsh, slope, gy_amax);
+  else if (planes == 2) hipLaunchKernelGGL((relayout_gy_kernel<2, false>), gg, dim3(256), 0, st, gy, gp, B, Cout, p.CoP, P, gsc, gsh, slope, gy_amax);
+  else hipLaunchKernelGGL((relayout_gy_kernel<3, false>), gg, dim3(256), 0, st, gy, gp, B, Cout, p.CoP, P, gsc, gsh, slope, gy_amax);
   VG_CHECK_LAUNCH();
   WXArgs A;
-  A.x = x; A.B = B; A.gp = gp; A.ws = slabs;
+  A.x = x; A.B = B; A.gp = gp; A.ws = slabs; A.x_amax = x_amax;
   A.in_scale = in_scale; A.in_shift = in_shift;
   A.in_slope = in_scale ? slope : 1.f;
   A.Cin = Cin; A.H = H; A.W = W; A.Cout = Cout; A.CoP = p.CoP; A.OH = p.OH; A.OW = p.OW;
@@ -564,12 +560,13 @@ extern "C" int vg_conv5x5_wgrad_bf16split(const float* x, const float* gy, float
   make_order(p, A.order);
   const long grid = p.wgs;
   int rc;
-  if (planes == 2) rc = (stride == 2) ? launch_wx_by_cout<2, 2>(A, p.wco, p.th, grid, st) : launch_wx_by_cout<1, 2>(A, p.wco, p.th, grid, st);
+  if (f16) rc = (stride == 2) ? launch_wx_by_cout<2, 2, true>(A, p.wco, p.th, grid, st) : launch_wx_by_cout<1, 2, true>(A, p.wco, p.th, grid, st);
+  else if (planes == 2) rc = (stride == 2) ? launch_wx_by_cout<2, 2>(A, p.wco, p.th, grid, st) : launch_wx_by_cout<1, 2>(A, p.wco, p.th, grid, st);
   else rc = (stride == 2) ? launch_wx_by_cout<2, 3>(A, p.wco, p.th, grid, st) : launch_wx_by_cout<1, 3>(A, p.wco, p.th, grid, st);
   if (rc) return rc;
   const unsigned n = (unsigned)Cout * Cin * 25;
   hipLaunchKernelGGL(wx_reduce_kernel, dim3(cdiv(n, 256u)), dim3(256), 0, st, slabs, dw, Cin, 32 * p.wco, p.mtiles,
-                     p.chunks, p.upw, n, accumulate ? 1 : 0);
+                     p.chunks, p.upw, n, accumulate ? 1 : 0, x_amax, gy_amax);
   VG_CHECK_LAUNCH();
   return 0;
 }

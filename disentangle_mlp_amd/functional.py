@@ -289,17 +289,20 @@ class BNConvFn(Function):
     def forward(ctx, x, gamma, beta, w, bias, running_mean, running_var, eps, momentum, act, stride, transposed,
                 bias_grad, stats_in):
         count = x.numel() // x.shape[1]
+        # bound: max |act(BN(x))| <= |gamma| sqrt(count) + |beta| (None outside the fp16-plane arithmetic): what the
+        # convolution -- and, in backward, the weight gradient -- scales the operand it reads through the BatchNorm by
         if stats_in is not None and stats_in.numel():
-            mean, invstd, scale, shift = ops.bn_finalize_stats(stats_in, count, gamma, beta, running_mean, running_var,
-                                                               eps, momentum)
+            mean, invstd, scale, shift, bound = ops.bn_finalize_stats(stats_in, count, gamma, beta, running_mean,
+                                                                      running_var, eps, momentum, want_bound=True)
         else:
-            mean, invstd, scale, shift = ops.bn_stats(x, gamma, beta, running_mean, running_var, eps, momentum)
+            mean, invstd, scale, shift, bound = ops.bn_stats(x, gamma, beta, running_mean, running_var, eps, momentum,
+                                                             want_bound=True)
         conv = ops.convT5x5_fwd if transposed else ops.conv5x5_fwd
-        y, stats = conv(x, w, bias, stride, in_affine=(scale, shift, act), want_stats=True)
+        y, stats = conv(x, w, bias, stride, in_affine=(scale, shift, act, bound), want_stats=True)
         stats = stats if stats is not None else x.new_empty(0)
         ctx.act, ctx.stride, ctx.transposed, ctx.bias_grad = act, stride, transposed, bias_grad
         ctx.acc = _acc_ctx()
-        ctx.save_for_backward(x, gamma, beta, mean, invstd, scale, shift, w)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd, scale, shift, w, bound)
         ctx.mark_non_differentiable(stats)
         ctx.set_materialize_grads(False)      # as ConvStatsFn
         return y, stats
@@ -309,7 +312,7 @@ class BNConvFn(Function):
     def backward(ctx, gy, _):
         if gy is None:
             return (None,) * 14
-        x, gamma, beta, mean, invstd, scale, shift, w = ctx.saved_tensors
+        x, gamma, beta, mean, invstd, scale, shift, w, bound = ctx.saved_tensors
         gy = gy.contiguous()
         s, tr, act = ctx.stride, ctx.transposed, ctx.act
         need_bn = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
@@ -324,7 +327,7 @@ class BNConvFn(Function):
             elif need_p:
                 _acc_put(ctx.acc, id(gamma), (dg, db))
         if ctx.needs_input_grad[3]:
-            aff = (scale, shift, act)
+            aff = (scale, shift, act, bound)
             prev = _acc_get(ctx.acc, id(w))
             kw = dict(out=prev, accumulate=True) if prev is not None else {}
             gw = ops.conv5x5_wgrad(gy, x, s, in_affine=aff, affine_on_gy=True, **kw) if tr \

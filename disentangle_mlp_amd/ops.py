@@ -103,26 +103,100 @@ def reserve_workspace(nbytes, device):
 USE_PACKED_FILTERS = True
 FP32_CONV_STATS = False     # see conv5x5_fwd
 # Arithmetic of the three convolution kernels (forward, transposed = data gradient, weight gradient):
-#   "bf16x6"  the product DEFAULT: every fp32 operand split exactly into 3 bf16 planes (8 + 8 + 8 mantissa bits),
-#             the 6 plane products whose indices sum to < 3 issued on the bf16 MFMA, fp32 accumulation:
-#             fp32-equivalent (4e-7..9e-7 vs fp64 per convolution, held to the same tolerances as the exact
-#             fp32-input MFMA, whose error is 5e-7..1e-6) at 1/2.7 of its matrix-pipe cost;
+#   "fp16x3"  the product DEFAULT: every fp32 operand, times an exact power of two taken from a bound of the tensor's
+#             largest magnitude, split into fp16 hi + lo (11 + 11 significand bits, residual <= 2^-24), the 3 plane
+#             products hi*hi, hi*lo, lo*hi on the f16 MFMA, fp32 accumulation, scales undone on the accumulators:
+#             fp32-equivalent (4e-7..6e-7 vs fp64 per convolution) at half the matrix work of bf16x6.  The bounds live in
+#             device memory (`amax_of`, producers emit them: bn_act_bwd, bn_finalize_stats, affine_act);
+#   "bf16x6"  OPT-IN: 3 bf16 planes (8 + 8 + 8 mantissa bits: exact, full fp32 range), 6 plane products:
+#             fp32-equivalent at any dynamic range (4e-7..9e-7 vs fp64), the default of rounds 2-3;
 #   "fp32"    OPT-IN: exact fp32-input MFMA (v_mfma_f32_32x32x2_f32), bit-for-bit a k-ordered fmaf chain;
-#   "bf16x3"  OPT-IN: 2 planes (hi/lo), 3 MFMAs per multiply, ~4.5e-6 relative error per convolution.
-# Layers whose input channels are not a multiple of 16 (the 3-channel edges) always run the fp32 kernels.
+#   "bf16x3"  OPT-IN: 2 bf16 planes (hi/lo), 3 MFMAs per multiply, ~4.5e-6 relative error per convolution.
+# The 3-channel edge layers (conv_thin_*.hip) run bf16x6 under fp16x3 too: they are bound by HBM and issue slots.
 # Set here, or with VG_CONV_ARITH in the environment.  DESIGN.md section 2.
-CONV_ARITH = __import__("os").environ.get("VG_CONV_ARITH", "bf16x6")
+CONV_ARITH = __import__("os").environ.get("VG_CONV_ARITH", "fp16x3")
 WGRAD_SPLIT = True      # within the split modes: False keeps the weight gradient on the exact-fp32 kernel
-if CONV_ARITH not in ("fp32", "bf16x3", "bf16x6"):
-    raise ImportError(f"VG_CONV_ARITH={CONV_ARITH!r}: expected 'fp32', 'bf16x3' or 'bf16x6'")
+if CONV_ARITH not in ("fp32", "bf16x3", "bf16x6", "fp16x3"):
+    raise ImportError(f"VG_CONV_ARITH={CONV_ARITH!r}: expected 'fp16x3', 'bf16x6', 'bf16x3' or 'fp32'")
 
 
 THIN_SPLIT = os.environ.get("VG_THIN_SPLIT", "1") != "0"   # 0: the 3-channel edge layers stay on the fp32 VALU / fp32-MFMA kernels in every arithmetic
+PLANES_F16 = 0x100      # VG_PLANES_F16 of include/vaegan_hip.h
 
 
 def _planes():
-    """bf16 operand planes of the active arithmetic: 0 (exact fp32 MFMA), 2 (bf16x3) or 3 (bf16x6)."""
-    return {"fp32": 0, "bf16x3": 2, "bf16x6": 3}[CONV_ARITH]
+    """`planes` argument of the split kernels for the active arithmetic: 0 (exact fp32 MFMA), 2 (bf16x3), 3 (bf16x6) or
+    2 | VG_PLANES_F16 (fp16x3)."""
+    return {"fp32": 0, "bf16x3": 2, "bf16x6": 3, "fp16x3": 2 | PLANES_F16}[CONV_ARITH]
+
+
+def _f16():
+    return CONV_ARITH == "fp16x3"
+
+
+def _thin_planes():
+    """The 3-channel edge kernels take bf16 planes only: bf16x6 under fp16x3."""
+    return 3 if _f16() else _planes()
+
+
+# ---- bounds of max |tensor| for the fp16 planes (csrc/absmax.hip) ---------------------------------------------------
+# A bound is a one-element fp32 device tensor.  Slots come zeroed from an arena (one fill launch per 512 of them); the
+# producing kernel adds its maximum with an atomic.  A tensor object remembers its bound (`_vg_amax`: the tensor's version
+# counter, what was applied on load, the slot), so that a gradient used by the data gradient AND the weight gradient, or
+# an input used forward and again by the weight gradient, is measured once.
+_AMAX_CHUNK = 512
+_amax_arenas = {}        # (device index, capturing) -> [chunk, next free]
+
+
+def _amax_slot(device):
+    key = (device.index, torch.cuda.is_current_stream_capturing())
+    a = _amax_arenas.get(key)
+    if a is None or a[1] >= _AMAX_CHUNK:
+        a = _amax_arenas[key] = [torch.zeros(_AMAX_CHUNK, dtype=torch.float32, device=device), 0]
+    a[1] += 1
+    return a[0][a[1] - 1:a[1]]
+
+
+class amax_capture_scope:
+    """Around a HIP-graph capture: the slots handed out inside come from chunks allocated -- and zero-filled -- INSIDE
+    the capture (a replay zeroes them again before its kernels add their maxima), and no slot of those chunks is handed
+    out once the capture has ended (a replay would zero it under an eager consumer)."""
+
+    def __enter__(self):
+        for k in [k for k in _amax_arenas if k[1]]:
+            del _amax_arenas[k]
+        return self
+
+    def __exit__(self, *exc):
+        for k in [k for k in _amax_arenas if k[1]]:
+            del _amax_arenas[k]
+        return False
+
+
+def set_amax(t, slot, in_affine=None):
+    """Remember ``slot`` as the bound of ``t`` (as read through ``in_affine``); returns ``slot``."""
+    t._vg_amax = (t._version, None if in_affine is None else id(in_affine[0]), slot)
+    return slot
+
+
+def amax_of(t, in_affine=None):
+    """Bound of max |t| -- of max |act(t * scale[c] + shift[c])| with ``in_affine`` = (scale, shift, act[, bound]) -- as a
+    one-element device tensor: the one a producer attached, the 4th element of ``in_affine``, or one pass over t."""
+    if in_affine is not None and len(in_affine) > 3 and in_affine[3] is not None:
+        return in_affine[3]
+    known = getattr(t, "_vg_amax", None)
+    tag = None if in_affine is None else id(in_affine[0])
+    if known is not None and known[0] == t._version and known[1] == tag:
+        return known[2]
+    lib = _lib.load()
+    slot = _amax_slot(t.device)
+    if in_affine is None:
+        check(lib.vg_absmax(t.data_ptr(), t.numel(), slot.data_ptr(), _stream()), "vg_absmax")
+    else:
+        B, C = t.shape[0], t.shape[1]
+        check(lib.vg_absmax_affine(t.data_ptr(), in_affine[0].data_ptr(), in_affine[1].data_ptr(), int(in_affine[2]), B, C,
+                                   t.numel() // (B * C), slot.data_ptr(), _stream()), "vg_absmax_affine")
+    return set_amax(t, slot, in_affine)
 
 
 def conv_runs_split(op, cin, cout=None, stride=None):
@@ -135,7 +209,7 @@ def conv_runs_split(op, cin, cout=None, stride=None):
     if cin <= 3 and op in ("conv_fwd", "conv_wgrad"):
         return THIN_SPLIT          # conv_thin_fwd.hip / conv_thin_wgrad.hip (shapes they take: output width % 32 / % 16)
     if op == "conv_wgrad":
-        return WGRAD_SPLIT and cin >= (16 if planes == 2 else 32)
+        return WGRAD_SPLIT and cin >= (16 if (planes & 0xff) == 2 else 32)
     if op == "convT_fwd" and stride == 1 and cout is not None and cout <= 4:
         return THIN_SPLIT and cin == 32 and cout <= 3          # conv_thin_mfma.hip
     return cin % 16 == 0
@@ -166,6 +240,14 @@ class packed_filter_scope:
         if _pack_scope_depth == 0:
             invalidate_packed_filters()
         return False
+
+
+def buffers_in_use():
+    """Every cached pack buffer and scratch buffer that exists now, as a list of tensors.  A HIP graph captured over
+    launches that read or write them holds raw device pointers: its owner keeps this list alive for as long as the graph
+    may be replayed, so that a cache rebuilt (`_PACK_CACHE_MAX`) or a workspace regrown by somebody else never hands the
+    memory a replay still writes to another tensor."""
+    return [ent[2] for ent in _pack_cache.values()] + list(_workspaces.values()) + list(_pack_scratch.values())
 
 
 def invalidate_packed_filters(params=None):
@@ -201,8 +283,12 @@ def _packed_filter(lib, w, cout, cin, transposed, stride):
         if buf is None:
             buf = _pack_scratch[skey] = torch.empty(n, dtype=torch.float32, device=w.device)
     if bf16x3:
+        wmax = None
+        if planes & PLANES_F16:          # a fresh (zeroed) slot per pack: the bound follows the weights down as well as up
+            wmax = _amax_slot(w.device)
+            check(lib.vg_absmax(w.data_ptr(), w.numel(), wmax.data_ptr(), _stream()), "vg_absmax")
         check(lib.vg_conv5x5_pack_bf16split(w.data_ptr(), buf.data_ptr(), cout, cin, transposed - 2, stride, planes,
-                                         _stream()), "vg_conv5x5_pack_bf16split")
+                                         _ptr(wmax), _stream()), "vg_conv5x5_pack_bf16split")
     else:
         check(lib.vg_conv5x5_pack(w.data_ptr(), buf.data_ptr(), cout, cin, transposed, stride, _stream()),
               "vg_conv5x5_pack")
@@ -254,8 +340,18 @@ def prepack_filters(requests):
     if not todo:
         return
     arr = (_lib.PackEntry * len(todo))()
+    wmax = {}
+    if planes & PLANES_F16:              # the filters' bounds first, all in one launch (one per weight, not per layout)
+        for (w, *_r) in todo:
+            if w.data_ptr() not in wmax:
+                wmax[w.data_ptr()] = (w, _amax_slot(w.device))
+        am = (_lib.AbsmaxEntry * len(wmax))()
+        for i, (w, slot) in enumerate(wmax.values()):
+            am[i] = _lib.AbsmaxEntry(w.data_ptr(), w.numel(), slot.data_ptr())
+        check(lib.vg_absmax_multi(am, len(wmax), _stream()), "vg_absmax_multi")
     for i, (w, ent, cout, cin, kind, stride) in enumerate(todo):
-        arr[i] = _lib.PackEntry(w.data_ptr(), ent[2].data_ptr(), cout, cin, kind - 2, stride)
+        slot = wmax[w.data_ptr()][1].data_ptr() if wmax else None
+        arr[i] = _lib.PackEntry(w.data_ptr(), ent[2].data_ptr(), cout, cin, kind - 2, stride, slot)
     check(lib.vg_conv5x5_pack_bf16split_multi(arr, len(todo), planes, _stream()), "vg_conv5x5_pack_bf16split_multi")
     for (w, ent, *_rest) in todo:
         ent[0], ent[1] = True, w._version
@@ -268,12 +364,16 @@ def conv_fusable(transposed, cin, cout, stride):
 
 
 def _fusion_struct(x, in_affine, stats):
-    """ctypes vg_conv_fusion (or None) + the tensors it points at (kept alive by the caller)."""
-    if in_affine is None and stats is None:
+    """ctypes vg_conv_fusion (or None) + the tensors it points at (kept alive by the caller).  fp16 planes: always, with
+    the bound of the input as the kernel reads it."""
+    if in_affine is None and stats is None and not _f16():
         return None
     f = _lib.ConvFusion()
+    if _f16():
+        f._amax = amax_of(x, in_affine)          # kept alive with the struct
+        f.in_amax = f._amax.data_ptr()
     if in_affine is not None:
-        scale, shift, act = in_affine
+        scale, shift, act = in_affine[:3]
         _req(scale, "in_scale"), _req(shift, "in_shift")
         if scale.numel() != x.shape[1] or shift.numel() != x.shape[1]:
             raise RuntimeError("in_affine: one coefficient per input channel")
@@ -285,7 +385,7 @@ def _fusion_struct(x, in_affine, stats):
 
 def _materialize(x, in_affine):
     """act(x * scale[c] + shift[c]) as a tensor: the fallback for kernels that cannot apply it on load."""
-    return x if in_affine is None else affine_act(x, *in_affine)
+    return x if in_affine is None else affine_act(x, *in_affine[:3])
 
 
 def conv5x5_fwd(x, w, bias, stride, in_affine=None, want_stats=False):
@@ -328,7 +428,7 @@ def conv5x5_fwd(x, w, bias, stride, in_affine=None, want_stats=False):
         stats = torch.empty(n, dtype=torch.float32, device=x.device) if n else None
         with _timed(("conv_fwd", B, Cin, H, W, Cout, stride)):
             check(lib.vg_conv5x5_thin_bf16split(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W, Cout,
-                                                stride, _planes(), _ptr(stats), n, _stream()), "vg_conv5x5_thin_bf16split")
+                                                stride, _thin_planes(), _ptr(stats), n, _stream()), "vg_conv5x5_thin_bf16split")
         return (y, stats) if want_stats else y
     if USE_PACKED_FILTERS:
         pk = _packed_filter(lib, w, Cout, Cin, 0, stride)
@@ -387,12 +487,12 @@ def convT5x5_fwd(x, w, bias, stride, in_affine=None, want_stats=False):
         return (y, stats) if want_stats else y
     if thin and _planes() and THIN_SPLIT and lib.vg_convT5x5_s1_thin_bf16split_ok(Cin, H, W, Cout):
         # 32 -> (<= 3) channels: filter resident in registers, one pass over x (BatchNorm + activation applied on load)
-        scale, shift, act = in_affine if in_affine is not None else (None, None, ACT_NONE)
+        scale, shift, act = in_affine[:3] if in_affine is not None else (None, None, ACT_NONE)
         if scale is not None:
             _req(scale, "in_scale"), _req(shift, "in_shift")
         with _timed(("convT_fwd", B, Cin, H, W, Cout, stride)):
             check(lib.vg_convT5x5_s1_thin_bf16split(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W, Cout,
-                                                    _planes(), _ptr(scale), _ptr(shift), int(act), _stream()),
+                                                    _thin_planes(), _ptr(scale), _ptr(shift), int(act), _stream()),
                   "vg_convT5x5_s1_thin_bf16split")
         return (y, None) if want_stats else y
     x = _materialize(x, in_affine)
@@ -426,28 +526,33 @@ def conv5x5_wgrad(x, gy, stride, out=None, in_affine=None, affine_on_gy=False, a
     dw = out if out is not None else torch.empty((Cout, Cin, 5, 5), dtype=torch.float32, device=x.device)
     # thin inputs stay on the exact-fp32 kernel: the re-layout of gy costs more than the split arithmetic saves
     # (measured: 2 planes pay off from 16 input channels, 3 planes from 32)
-    if _planes() and WGRAD_SPLIT and Cin >= (16 if _planes() == 2 else 32):
+    if _planes() and WGRAD_SPLIT and Cin >= (16 if (_planes() & 0xff) == 2 else 32):
         need = lib.vg_conv5x5_wgrad_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride, _planes())    # 0: shape not taken
         if need:
             ws = workspace(need, x.device)
-            sc, sh, act = in_affine if in_affine is not None else (None, None, 0)
+            sc, sh, act = in_affine[:3] if in_affine is not None else (None, None, 0)
+            xmax = gmax = None
+            if _f16():       # bounds of the two operands as the kernel reads them
+                xmax = amax_of(x, None if affine_on_gy else in_affine)
+                gmax = amax_of(gy, in_affine if affine_on_gy else None)
             with _timed(("conv_wgrad", B, Cin, H, W, Cout, stride)):
                 check(lib.vg_conv5x5_wgrad_bf16split(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout, stride,
                                                   _planes(), ws.data_ptr(), ws.numel(), _ptr(sc), _ptr(sh), int(act),
-                                                  1 if affine_on_gy else 0, acc, _stream()), "vg_conv5x5_wgrad_bf16split")
+                                                  1 if affine_on_gy else 0, _ptr(xmax), _ptr(gmax), acc, _stream()),
+                      "vg_conv5x5_wgrad_bf16split")
             return dw
     if _planes() and THIN_SPLIT and Cin <= 3 and (in_affine is None or affine_on_gy):
         # <= 3 input channels: one read pass over gy (a producer's BatchNorm + activation applied to it on load: the weight
         # gradient of the decoder's last layer), x split once per workgroup into shifted plane copies in LDS
-        need = lib.vg_conv5x5_thin_wgrad_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride, _planes())   # 0: shape not taken
+        need = lib.vg_conv5x5_thin_wgrad_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride, _thin_planes())   # 0: shape not taken
         if need:
             ws = workspace(need, x.device)
-            sc, sh, act = in_affine if in_affine is not None else (None, None, 0)
+            sc, sh, act = in_affine[:3] if in_affine is not None else (None, None, 0)
             if sc is not None:
                 _req(sc, "in_scale"), _req(sh, "in_shift")
             with _timed(("conv_wgrad", B, Cin, H, W, Cout, stride)):
                 check(lib.vg_conv5x5_thin_wgrad_bf16split(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout,
-                                                          stride, _planes(), ws.data_ptr(), ws.numel(), _ptr(sc), _ptr(sh),
+                                                          stride, _thin_planes(), ws.data_ptr(), ws.numel(), _ptr(sc), _ptr(sh),
                                                           int(act), acc, _stream()), "vg_conv5x5_thin_wgrad_bf16split")
             return dw
     if in_affine is not None:      # the kernels below take the operand as a tensor
@@ -456,12 +561,12 @@ def conv5x5_wgrad(x, gy, stride, out=None, in_affine=None, affine_on_gy=False, a
         else:
             x = _materialize(x, in_affine)
     if _planes() and THIN_SPLIT and Cin <= 3:
-        need = lib.vg_conv5x5_thin_wgrad_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride, _planes())
+        need = lib.vg_conv5x5_thin_wgrad_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride, _thin_planes())
         if need:
             ws = workspace(need, x.device)
             with _timed(("conv_wgrad", B, Cin, H, W, Cout, stride)):
                 check(lib.vg_conv5x5_thin_wgrad_bf16split(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout,
-                                                          stride, _planes(), ws.data_ptr(), ws.numel(), None, None, 0, acc,
+                                                          stride, _thin_planes(), ws.data_ptr(), ws.numel(), None, None, 0, acc,
                                                           _stream()), "vg_conv5x5_thin_wgrad_bf16split")
             return dw
     need = lib.vg_conv5x5_wgrad_workspace_bytes(B, Cin, H, W, Cout, stride)
@@ -500,24 +605,27 @@ def bn_act_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, act):
     return y, mean, invstd
 
 
-def bn_finalize_stats(stats, count, gamma, beta, running_mean, running_var, eps, momentum):
+def bn_finalize_stats(stats, count, gamma, beta, running_mean, running_var, eps, momentum, want_bound=False):
     """Coefficients of a train-mode BatchNorm from a convolution's statistics slots (``stats`` from
-    conv5x5_fwd / convT5x5_fwd with want_stats): (mean, invstd, scale, shift); running statistics updated in place."""
+    conv5x5_fwd / convT5x5_fwd with want_stats): (mean, invstd, scale, shift); running statistics updated in place.
+    ``want_bound``: a 5th result, the bound of max |act(BN(x))| an fp16-plane consumer needs (None in other arithmetics) --
+    from the coefficients alone, no pass over x."""
     lib = _lib.load()
     _req(stats, "stats"), _req(gamma, "gamma"), _req(beta, "beta")
     C = gamma.numel()
     nslots = stats.numel() // (2 * C)
     out = torch.empty((4, C), dtype=torch.float32, device=gamma.device)
     mean, invstd, scale, shift = out[0], out[1], out[2], out[3]
+    bound = _amax_slot(gamma.device) if (want_bound and _f16()) else None
     ws = workspace(lib.vg_bn_workspace_bytes(C), gamma.device)
     check(lib.vg_bn_finalize_stats(stats.data_ptr(), nslots, C, float(count), gamma.data_ptr(), beta.data_ptr(),
                                    _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(),
-                                   scale.data_ptr(), shift.data_ptr(), eps, momentum, ws.data_ptr(), ws.numel(), _stream()),
-          "vg_bn_finalize_stats")
-    return mean, invstd, scale, shift
+                                   scale.data_ptr(), shift.data_ptr(), eps, momentum, _ptr(bound), ws.data_ptr(), ws.numel(),
+                                   _stream()), "vg_bn_finalize_stats")
+    return (mean, invstd, scale, shift, bound) if want_bound else (mean, invstd, scale, shift)
 
 
-def bn_stats(x, gamma, beta, running_mean, running_var, eps, momentum):
+def bn_stats(x, gamma, beta, running_mean, running_var, eps, momentum, want_bound=False):
     """The same coefficients from a pass over x (layers whose producer leaves no statistics)."""
     lib = _lib.load()
     _req(x, "x"), _req(gamma, "gamma"), _req(beta, "beta")
@@ -525,11 +633,12 @@ def bn_stats(x, gamma, beta, running_mean, running_var, eps, momentum):
     HW = x.numel() // (B * C)
     out = torch.empty((4, C), dtype=torch.float32, device=x.device)
     mean, invstd, scale, shift = out[0], out[1], out[2], out[3]
+    bound = _amax_slot(x.device) if (want_bound and _f16()) else None
     ws = workspace(lib.vg_bn_workspace_bytes(C), x.device)
     check(lib.vg_bn_stats(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(running_mean), _ptr(running_var),
                           mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), B, C, HW, eps, momentum,
-                          ws.data_ptr(), ws.numel(), _stream()), "vg_bn_stats")
-    return mean, invstd, scale, shift
+                          _ptr(bound), ws.data_ptr(), ws.numel(), _stream()), "vg_bn_stats")
+    return (mean, invstd, scale, shift, bound) if want_bound else (mean, invstd, scale, shift)
 
 
 def affine_act(x, scale, shift, act):
@@ -539,8 +648,11 @@ def affine_act(x, scale, shift, act):
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
     y = torch.empty_like(x)
-    check(lib.vg_affine_act(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), B, C, HW, int(act), _stream()),
-          "vg_affine_act")
+    slot = _amax_slot(x.device) if _f16() else None          # max |y| on the way out: y feeds a convolution
+    check(lib.vg_affine_act(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), B, C, HW, int(act), _ptr(slot),
+                            _stream()), "vg_affine_act")
+    if slot is not None:
+        set_amax(y, slot)
     return y
 
 
@@ -558,9 +670,13 @@ def bn_act_bwd(gy, x, gamma, beta, mean, invstd, act, need_param_grads=True, acc
         dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if need_param_grads else None
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if need_param_grads else None
     ws = workspace(lib.vg_bn_workspace_bytes(C), x.device)
+    slot = _amax_slot(x.device) if (_f16() and HW > 1) else None   # max |gx| on the way out: gx feeds a data / weight gradient
     check(lib.vg_bn_act_bwd(gy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
                             invstd.data_ptr(), gx.data_ptr(), _ptr(dgamma), _ptr(dbeta), B, C, HW, act,
-                            1 if accumulate_into is not None else 0, ws.data_ptr(), ws.numel(), _stream()), "vg_bn_act_bwd")
+                            1 if accumulate_into is not None else 0, _ptr(slot), ws.data_ptr(), ws.numel(), _stream()),
+          "vg_bn_act_bwd")
+    if slot is not None:
+        set_amax(gx, slot)
     return gx, dgamma, dbeta
 
 

@@ -97,6 +97,35 @@ class HipAdam(optim.Adam):
         return super().load_state_dict(state_dict)
 
     @torch.no_grad()
+    def load_state_in_place(self, state_dict):
+        """`load_state_dict` that COPIES into the existing moment tensors (same parameters, same shapes) instead of
+        replacing them: an iteration captured in a HIP graph stays valid (`state_generation` does not change).  Parameters
+        absent from ``state_dict`` (a checkpoint taken before the first step) go back to step 0 with zero moments."""
+        self._flush_replays()
+        src = state_dict["state"]
+        i = 0
+        for gi, group in enumerate(self.param_groups):
+            steps = set()
+            for p in group["params"]:
+                mine, theirs = self.state[p], src.get(i)
+                i += 1
+                if not len(mine):
+                    if theirs:
+                        raise RuntimeError("HipAdam.load_state_in_place: no state to copy into (use load_state_dict)")
+                    continue
+                if theirs:
+                    mine["step"].fill_(float(theirs["step"]))
+                    mine["exp_avg"].copy_(theirs["exp_avg"])
+                    mine["exp_avg_sq"].copy_(theirs["exp_avg_sq"])
+                else:
+                    mine["step"].zero_()
+                    mine["exp_avg"].zero_()
+                    mine["exp_avg_sq"].zero_()
+                steps.add(float(mine["step"]))
+            if gi in self._dev and len(steps) == 1:
+                self._dev[gi][0].fill_(steps.pop())          # the device counter a replayed step advances
+
+    @torch.no_grad()
     def step(self, closure=None):
         if closure is not None or not all(self._native_ok(g) for g in self.param_groups):
             if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():

@@ -301,7 +301,7 @@ class _CapturedIteration:
         for o in optimizers:
             o.prepare_capture()
         try:
-            with torch.cuda.graph(self.graph):
+            with ops.amax_capture_scope(), torch.cuda.graph(self.graph):
                 self.out = run(self.inputs, self.labels[0:1], self.labels[1:2])
         except Exception:
             # nothing executed: take back what the pass did on the host side
@@ -312,6 +312,8 @@ class _CapturedIteration:
                     o.state[p]["step"].fill_(v)
                 o._captured = []
             raise
+        # the graph holds raw pointers into the pack cache and the scratch buffers of ops: they live as long as it does
+        self._buffers = ops.buffers_in_use()
         self.nbt_delta = [m._nbt_pending - n for m, n in zip(bn_modules, before_nbt)]
         self.fresh = True          # the capture pass already did the host-side bookkeeping of the first replay
 
@@ -346,6 +348,7 @@ class _GraphedSteps:
     replay at all) and `_run_graphed` (warm-up count per shape, capture, replay, fallback)."""
     graph = False
     iteration = 0
+    probe = None      # callable(name, tensor): taps of an (eager) iteration, see BetaVAEGANTrainer._phases
 
     def _graph_init(self, graph, on_gpu, fused_adam, dp):
         self.graph = (GRAPH_DEFAULT if graph is None else bool(graph)) and on_gpu and fused_adam and not dp
@@ -376,7 +379,7 @@ class _GraphedSteps:
                                                           else [r for v in plans.values() for r in v]))
 
     def _graph_usable(self, optimizers, data, grad_hook):
-        return (self.graph and grad_hook is None and ops._timing is None and data.is_cuda
+        return (self.graph and grad_hook is None and self.probe is None and ops._timing is None and data.is_cuda
                 and all(isinstance(o, HipAdam) and o.device_scalars for o in optimizers)
                 and not torch.cuda.is_current_stream_capturing())
 
@@ -543,6 +546,8 @@ class BetaVAEGANTrainer(_GraphedSteps):
         # ---- phase 1: discriminator (:95-123)
         self._zero(netD, self.flat_d)
         fake = netEG.decode(noise)                           # graph kept for phase 2 (:113)
+        if self.probe is not None and fake.requires_grad:    # diagnostics (bench.py `regime`): such an iteration is eager
+            fake.register_hook(lambda g: self.probe("grad_wrt_fake", g))
         with F.deferred_wgrad():                             # D runs twice, one backward: big Linear weight gradient once
             p_real, _, err_real = netD.forward_with_bce(data, real_label, gb)
             p_fake, _, err_fake = netD.forward_with_bce(fake.detach(), fake_label, gb)
@@ -722,6 +727,29 @@ class BetaVAEGANTrainer(_GraphedSteps):
         self.netD.load_state_dict(d_sd)
         self.optimizerEG.load_state_dict(ck["encoder_decoder_optimizer"])
         self.optimizerD.load_state_dict(ck["discriminator_optimizer"])
+        return ck["epoch"]
+
+    @torch.no_grad()
+    def load_in_place(self, ck):
+        """`load` of a checkpoint dict of THIS trainer's shapes that copies into the existing parameter, buffer and moment
+        tensors: a captured iteration stays valid and the next `step` replays it from the loaded state (bench.py times
+        from the initial state this way).  The packs a replay does not rewrite itself are rewritten here."""
+        d_sd = ck["discriminator_model"]
+        if all(k.startswith("module.") for k in d_sd):
+            d_sd = {k[len("module."):]: v for k, v in d_sd.items()}
+        for net, sd in ((self.netEG, ck["encoder_decoder_model"]), (self.netD, d_sd)):
+            for k, v in net.state_dict().items():            # (flushes the lazily counted num_batches_tracked)
+                v.copy_(sd[k])
+        if isinstance(self.optimizerEG, HipAdam) and isinstance(self.optimizerD, HipAdam):
+            self.optimizerEG.load_state_in_place(ck["encoder_decoder_optimizer"])
+            self.optimizerD.load_state_in_place(ck["discriminator_optimizer"])
+        else:
+            self.optimizerEG.load_state_dict(ck["encoder_decoder_optimizer"])
+            self.optimizerD.load_state_dict(ck["discriminator_optimizer"])
+        ops.invalidate_packed_filters()
+        if self._pack_plans is not None:
+            with ops.packed_filter_scope():
+                ops.prepack_filters([r for v in self._pack_plans.values() for r in v])
         return ck["epoch"]
 
 

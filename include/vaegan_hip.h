@@ -43,8 +43,8 @@ extern "C" {
 /* ABI version of this header: bumped on every incompatible change of a signature, of a packed-filter layout or of a
  * workspace contract.  vg_version() returns the value the library was built with; a binding must refuse a library
  * whose version is not the header's (the .so files are build products that travel with the working tree: a stale one
- * still exports every old symbol).  3: round 3. */
-#define VG_ABI_VERSION 3
+ * still exports every old symbol).  3: round 3.  4: round 4 (fp16 planes: VG_PLANES_F16, the *_amax arguments). */
+#define VG_ABI_VERSION 4
 int vg_version(void);
 
 /* ---- 5x5 convolutions, padding 2, stride 1 or 2 ----------------------------
@@ -88,13 +88,22 @@ int vg_conv5x5_fwd_packed_stats(const float* x, const float* packed, const float
                                 int B, int Cin, int H, int W, int Cout, int stride,
                                 float* stats, size_t stats_floats, void* stream);
 
-/* Split-bf16 arithmetic of vg_conv5x5_fwd / vg_convT5x5_fwd: every fp32 operand is split
- * into `planes` bf16 values and the products whose plane indices sum to < planes are evaluated on the bf16
- * MFMA (v_mfma_f32_32x32x16_bf16) with fp32 accumulation:
- *   planes = 3  hi/mid/lo = the whole 24-bit mantissa, 6 MFMAs per product ("bf16x6"): every dropped
- *               term is below 2^-24 -- fp32-equivalent (4e-7..9e-7 against fp64; the exact fp32-input
- *               MFMA kernels above: 5e-7..1e-6).  THE PRODUCT DEFAULT of the Python layer.
- *   planes = 2  hi/lo, 3 MFMAs per product ("bf16x3"): ~4.5e-6 relative error; opt-in.
+/* Split arithmetics of vg_conv5x5_fwd / vg_convT5x5_fwd: every fp32 operand is split
+ * into `planes` 16-bit values and the products whose plane indices sum to < planes are evaluated on the 16-bit
+ * MFMA (v_mfma_f32_32x32x16_bf16 / _f16) with fp32 accumulation:
+ *   planes = 2 | VG_PLANES_F16   fp16 hi/lo = 11 + 11 significand bits (residual <= 2^-24 relative), 3 MFMAs per product
+ *               ("fp16x3"): fp32-equivalent (4e-7..6e-7 against fp64) at half the matrix work of bf16x6.  fp16 has 5
+ *               exponent bits: each operand tensor is multiplied by an exact power of two taken from an UPPER BOUND of
+ *               its largest magnitude, which the caller supplies in device memory (vg_conv_fusion.in_amax, the *_amax
+ *               arguments below; vg_absmax* compute one, vg_bn_act_bwd / vg_bn_finalize_stats / vg_affine_act emit one
+ *               on their way out); the scales are undone on the fp32 accumulators.  A bound that is too small overflows
+ *               fp16 (inf / NaN in the output, never a silently wrong number); elements more than 2^-16 below the bound
+ *               keep fewer than 22 bits: their error is bounded by 2^-40 of the bound.  THE PRODUCT DEFAULT of the
+ *               Python layer.
+ *   planes = 3  bf16 hi/mid/lo = the whole 24-bit mantissa, 6 MFMAs per product ("bf16x6"): every dropped
+ *               term is below 2^-24 -- fp32-equivalent at any dynamic range (4e-7..9e-7 against fp64; the exact
+ *               fp32-input MFMA kernels above: 5e-7..1e-6).  Opt-in; the 3-channel edge kernels always use it.
+ *   planes = 2  bf16 hi/lo, 3 MFMAs per product ("bf16x3"): ~4.5e-6 relative error; opt-in.
  * Requires Cin % 16 == 0.  `packed` holds vg_conv5x5_packed_bf16split_bytes(Cout, Cin, planes) bytes
  * (16-byte aligned), written by vg_conv5x5_pack_bf16split once per weight version:
  *   transposed = 0: from w[Cout,Cin,5,5] for vg_conv5x5_fwd_bf16split with the SAME stride (the stride-2
@@ -113,25 +122,32 @@ int vg_conv5x5_fwd_packed_stats(const float* x, const float* packed, const float
  *     into the next BatchNorm's coefficients.  NULL: none.
  * vg_conv5x5_bf16split_fusable says whether a layer's kernel takes a non-empty fusion; *_stats_floats returns 0 for
  * layers that cannot emit statistics (other kernels, K-split layers). */
+#define VG_PLANES_F16 0x100 /* flag of the `planes` arguments: the planes are IEEE half precision (with 2 planes only) */
 typedef struct vg_conv_fusion {
   const float* in_scale;
   const float* in_shift;
   int in_act;
   float* stats;
   size_t stats_floats;
+  /* fp16 planes (required then, ignored otherwise; not a fusion: every kernel of the family takes it): in_amax[0], DEVICE
+   * memory, >= the largest |value| of the input as the kernel reads it (after in_scale / in_shift / in_act) */
+  const float* in_amax;
 } vg_conv_fusion;
 int vg_conv5x5_bf16split_fusable(int transposed, int Cin, int Cout, int stride);
 size_t vg_conv5x5_fwd_bf16split_stats_floats(int B, int Cin, int H, int W, int Cout, int stride);
 size_t vg_convT5x5_fwd_bf16split_stats_floats(int B, int Cin, int H, int W, int Cout, int stride);
 size_t vg_conv5x5_packed_bf16split_bytes(int Cout, int Cin, int planes);
+/* w_amax (fp16 planes; NULL otherwise): w_amax[0] >= max |w|, DEVICE memory (vg_absmax / vg_absmax_multi); the pack
+ * keeps the inverse of the filter's scale in a 16-byte trailer for the convolution's epilogue */
 int vg_conv5x5_pack_bf16split(const float* w, void* packed, int Cout, int Cin, int transposed, int stride,
-                           int planes, void* stream);
+                           int planes, const float* w_amax, void* stream);
 /* The same for several filters in one launch (`entries` is a HOST array; 24 filters per kernel launch): what a
  * training iteration calls after each optimizer step for every filter that step has changed. */
 typedef struct {
   const float* w;
   void* packed;
   int Cout, Cin, transposed, stride;
+  const float* w_amax; /* as vg_conv5x5_pack_bf16split */
 } VgPackEntry;
 int vg_conv5x5_pack_bf16split_multi(const VgPackEntry* entries, int count, int planes, void* stream);
 size_t vg_conv5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride);
@@ -183,10 +199,27 @@ size_t vg_conv5x5_wgrad_bf16split_workspace_bytes(int B, int Cin, int H, int W, 
 int vg_conv5x5_wgrad_bf16split(const float* x, const float* gy, float* dw, int B, int Cin, int H, int W,
                             int Cout, int stride, int planes, void* workspace, size_t workspace_bytes,
                             const float* in_scale, const float* in_shift, int in_act, int affine_on_gy,
+                            /* fp16 planes (NULL otherwise): x_amax[0] >= max |x|, gy_amax[0] >= max |gy|, each of the
+                             * operand as the kernel reads it (after the affine + activation where one applies), DEVICE */
+                            const float* x_amax, const float* gy_amax,
                             int accumulate /* dw += (see vg_conv5x5_wgrad) */, void* stream);
 /* in_scale / in_shift / in_act: one operand is read as act(v * scale[c] + shift[c]) (vg_conv_fusion semantics) --
  * x (Cin coefficients) when affine_on_gy == 0, gy (Cout coefficients; the weight gradient of a transposed
  * convolution passes the layer's input there) otherwise.  NULL, NULL, 0, 0: both operands as they are. */
+
+/* Bounds for the fp16 planes: amax[0] = max(amax[0], max |x|) over n floats -- an atomic maximum on the bit pattern
+ * (order-independent; a NaN in x ends up in the bound); the caller zeroes amax[0] first (or keeps accumulating a bound
+ * over several tensors).  _affine: over act(x[b][c][hw] * scale[c] + shift[c]) (vg_conv_fusion semantics).  _multi: many
+ * tensors in one launch (`entries` is a HOST array) -- the filters an optimizer step has changed. */
+int vg_absmax(const float* x, size_t n, float* amax, void* stream);
+int vg_absmax_affine(const float* x, const float* scale, const float* shift, int act, int B, int C, int HW, float* amax,
+                     void* stream);
+typedef struct {
+  const float* x;
+  size_t n;
+  float* amax;
+} VgAbsmaxEntry;
+int vg_absmax_multi(const VgAbsmaxEntry* entries, int count, void* stream);
 
 /* dw[Cout,Cin,5,5] = sum_{b,oh,ow} gy[b,co,oh,ow] * x[b,ci,s*oh+kh-2,s*ow+kw-2].
  * Weight gradient of nn.Conv2d (autograd of model.py:450...; new_betavaegan.py:103,121)
@@ -227,6 +260,7 @@ int vg_bn_act_bwd(const float* gy, const float* x, const float* gamma, const flo
                   float* gx, float* dgamma, float* dbeta,
                   int B, int C, int HW, int act,
                   int accumulate_param_grads /* dgamma, dbeta += (a layer used twice before one backward) */,
+                  float* gx_amax /* NULL, or DEVICE: gx_amax[0] = max(gx_amax[0], max |gx|) -- see vg_absmax */,
                   void* workspace, size_t workspace_bytes, void* stream);
 /* Fused-BatchNorm helpers.  vg_bn_finalize_stats turns a convolution's statistics slots
  * ([nslots][C][2] floats: vg_conv_fusion.stats) into the coefficients of the train-mode BatchNorm that follows it
@@ -234,16 +268,20 @@ int vg_bn_act_bwd(const float* gy, const float* x, const float* gamma, const flo
  * in_scale / in_shift -- and updates the running statistics (momentum, unbiased variance) as vg_bn_act_fwd does;
  * count = B * H * W.  vg_bn_stats does the same from a pass over x (layers whose producer cannot emit statistics).
  * vg_affine_act materialises y = act(x * scale[c] + shift[c]) (16-byte accesses when HW % 4 == 0) for consumers that cannot apply the
- * coefficients while they load. */
+ * coefficients while they load.
+ * act_amax (NULL, or DEVICE, zeroed by the caller): receives an upper bound of max |act(BN(x))| over the tensor -- from
+ * the coefficients alone (|x - mean| <= sigma sqrt(count - 1), so |BN(x)| <= |gamma| sqrt(count) + |beta|): what an
+ * fp16-plane convolution that applies scale / shift on load needs as vg_conv_fusion.in_amax, without a pass over x.
+ * y_amax of vg_affine_act: the exact max |y| (see vg_absmax). */
 int vg_bn_finalize_stats(const float* stats, int nslots, int C, double count, const float* gamma, const float* beta,
                          float* running_mean, float* running_var, float* save_mean, float* save_invstd,
-                         float* scale, float* shift, float eps, float momentum,
+                         float* scale, float* shift, float eps, float momentum, float* act_amax,
                          void* workspace, size_t workspace_bytes, /* vg_bn_workspace_bytes(C) */ void* stream);
 int vg_bn_stats(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                 float* save_mean, float* save_invstd, float* scale, float* shift, int B, int C, int HW,
-                float eps, float momentum, void* workspace, size_t workspace_bytes, void* stream);
+                float eps, float momentum, float* act_amax, void* workspace, size_t workspace_bytes, void* stream);
 int vg_affine_act(const float* x, const float* scale, const float* shift, float* y, int B, int C, int HW, int act,
-                  void* stream);
+                  float* y_amax, void* stream);
 
 
 /* ---- elementwise activations ------------------------------------------------

@@ -12,10 +12,11 @@ from oracle import ops as O
 
 pytestmark = pytest.mark.gpu
 
-# Convolution tolerance (relative L2 against the fp64 oracle): 3e-6 for the default arithmetic (bf16x6: the exact
-# 3-plane split of every fp32 operand, fp32 accumulate) AND for the exact fp32-input MFMA kernels (opt-in "fp32");
-# 2e-5 only when the suite is run with VG_CONV_ARITH=bf16x3 exported (the opt-in 2-plane split).
-CONV_TOL = 2e-5 if os.environ.get("VG_CONV_ARITH", "bf16x6") == "bf16x3" else 3e-6
+# Convolution tolerance (relative L2 against the fp64 oracle): 3e-6 for the default arithmetic (fp16x3: fp16 hi/lo split
+# of every scaled fp32 operand, 3 MFMAs per multiply, fp32 accumulate), for bf16x6 (the exact 3-plane bf16 split, the
+# default of rounds 2-3) AND for the exact fp32-input MFMA kernels (opt-in "fp32"); 2e-5 only when the suite is run with
+# VG_CONV_ARITH=bf16x3 exported (the opt-in 2-plane bf16 split).
+CONV_TOL = 2e-5 if os.environ.get("VG_CONV_ARITH", "fp16x3") == "bf16x3" else 3e-6
 
 
 @pytest.fixture(scope="module")
@@ -24,10 +25,10 @@ def H():
     return ops
 
 
-@pytest.fixture(params=["default", "fp32"])
+@pytest.fixture(params=["default", "fp32", "bf16x6"])
 def conv_arith(request, H):
-    """Runs a convolution test twice: in the product's default arithmetic and on the exact fp32-input MFMA
-    kernels (ops.CONV_ARITH = "fp32"), both held to CONV_TOL."""
+    """Runs a convolution test three times: in the product's default arithmetic (fp16x3), on the exact fp32-input MFMA
+    kernels (ops.CONV_ARITH = "fp32") and in bf16x6, all held to CONV_TOL."""
     prev = H.CONV_ARITH
     if request.param != "default":
         H.CONV_ARITH = request.param
@@ -679,6 +680,106 @@ def test_bf16x6_is_fp32_equivalent(H, B, Cin, Cout, Hs, Ws, stride):
         H.CONV_ARITH = prev_arith
 
 
+# ------------------------------------------------------------------ fp16x3: the default, fp32-equivalent on 3 MFMAs
+@pytest.mark.parametrize("B,Cin,Cout,Hs,Ws,stride", [
+    (3, 16, 32, 16, 16, 2), (2, 128, 256, 32, 32, 2), (5, 48, 70, 13, 9, 2), (3, 16, 130, 16, 24, 1),
+    (16, 256, 256, 16, 16, 2), (20, 32, 128, 16, 32, 2)])
+def test_fp16x3_is_fp32_equivalent(H, B, Cin, Cout, Hs, Ws, stride):
+    """ops.CONV_ARITH = "fp16x3": every operand times a power of two from a bound of its largest magnitude, split into
+    fp16 hi + lo (11 + 11 bits), hi*hi + hi*lo + lo*hi on the f16 MFMA, fp32 accumulation.  Held to the SAME 3e-6 as
+    the exact-fp32 kernels and bf16x6 -- forward, transposed (= data gradient) and weight gradient -- on operands whose
+    magnitudes sit far from 1 (the scales have something to do: x ~ 3e3, w ~ 2e-4, gy ~ 1e-5)."""
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn(B, Cin, Hs, Ws, generator=g) * 3e3
+    w = torch.randn(Cout, Cin, 5, 5, generator=g) * 2e-4
+    wt = torch.randn(Cin, Cout, 5, 5, generator=g) * 2e-4
+    bias = torch.randn(Cout, generator=g)
+    y_ref = O.conv5x5(x, w, bias, stride)
+    gy = torch.randn(*y_ref.shape, generator=g) * 1e-5
+    gx_ref, gw_ref = O.conv5x5_grads(x, w, gy, stride)
+    prev_arith = H.CONV_ARITH
+    try:
+        H.CONV_ARITH = "fp16x3"
+        assert_close(H.conv5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), stride), y_ref, 3e-6, "fp16x3 fwd")
+        assert_close(H.convT5x5_fwd(x.cuda(), wt.cuda(), bias.cuda(), stride), O.convT5x5(x, wt, bias, stride), 3e-6,
+                     "fp16x3 convT")
+        if gx_ref.shape[2] == gy.shape[2] * stride and gx_ref.shape[3] == gy.shape[3] * stride:
+            assert_close(H.convT5x5_fwd(gy.cuda(), w.cuda(), None, stride), gx_ref, 3e-6, "fp16x3 dgrad")
+        assert_close(H.conv5x5_wgrad(x.cuda(), gy.cuda(), stride), gw_ref, 3e-6, "fp16x3 wgrad")
+    finally:
+        H.CONV_ARITH = prev_arith
+
+
+@pytest.mark.parametrize("kind", ["images spanning 1e-8..1e2", "saturated discriminator"])
+def test_fp16x3_on_wide_range_gradients(H, kind):
+    """The range fp16's 5 exponent bits have to cover in a training iteration: (a) a gradient tensor whose images span ten
+    decades (1e-8 ... 1e2: per-image BCE / Dis_l gradients of very different size in one batch), (b) the gradient that a
+    saturated discriminator sends back -- almost all exact zeros, a few elements at 1e-12 ... 1e-6.  Data gradient and
+    weight gradient of conv 128 -> 256 stride 2 at CONV_TOL over the tensor; for (a) also image by image, where the bound
+    fp16x3 promises is the absolute one (2^-40 of the tensor's largest magnitude): images within
+    2^-16 of the largest keep the relative 3e-6."""
+    g = torch.Generator().manual_seed(16)
+    B, Cin, Cout, Hs, s = 12, 128, 256, 16, 2
+    x = torch.randn(B, Cin, Hs, Hs, generator=g).clamp(min=0)
+    w = torch.randn(Cout, Cin, 5, 5, generator=g) * 0.02
+    gy = torch.randn(B, Cout, Hs // s, Hs // s, generator=g)
+    if kind.startswith("images"):
+        scales = torch.logspace(-8, 2, B)
+        gy = gy * scales.view(-1, 1, 1, 1)
+    else:
+        keep = torch.rand(gy.shape, generator=g) < 1e-3
+        gy = torch.where(keep, gy * torch.logspace(-12, -6, gy.numel()).view(gy.shape), torch.zeros(()))
+    gx_ref, gw_ref = O.conv5x5_grads(x, w, gy, s)
+    prev_arith = H.CONV_ARITH
+    try:
+        H.CONV_ARITH = "fp16x3"
+        gx = H.convT5x5_fwd(gy.cuda(), w.cuda(), None, s)
+        gw = H.conv5x5_wgrad(x.cuda(), gy.cuda(), s)
+    finally:
+        H.CONV_ARITH = prev_arith
+    assert_close(gx, gx_ref, CONV_TOL, f"fp16x3 dgrad, {kind}")
+    assert_close(gw, gw_ref, CONV_TOL, f"fp16x3 wgrad, {kind}")
+    if kind.startswith("images"):
+        top = float(gx_ref.abs().max())
+        for b in range(B):
+            err = float((gx[b].double().cpu() - gx_ref[b].double()).norm())
+            ref = float(gx_ref[b].double().norm())
+            # relative 3e-6 of the image, or -- far below the largest image -- 2^-36 of the tensor's largest value per
+            # element (K = 3200 products, each with an absolute error <= 2^-40 of the bound times the filter's size)
+            assert err <= 3e-6 * ref + 2.0 ** -36 * top * gx_ref[b].numel() ** 0.5, (b, err, ref, top)
+
+
+def test_fp16x3_bound_too_small_is_loud(H):
+    """A bound below the data overflows fp16: the output carries inf / NaN, never a finite wrong number; a NaN in the
+    data reaches the bound (vg_absmax orders bit patterns) and the output."""
+    import ctypes
+    from disentangle_mlp_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(17)
+    x = (torch.randn(2, 16, 16, 16, generator=g) * 100).cuda()
+    w = (torch.randn(32, 16, 5, 5, generator=g) * 0.05).cuda()
+    prev_arith = H.CONV_ARITH
+    try:
+        H.CONV_ARITH = "fp16x3"
+        H.set_amax(x, torch.full((1,), 1e-3, device="cuda"))            # a lie: the data reaches 400
+        y = H.conv5x5_fwd(x, w, None, 2)
+        assert not bool(torch.isfinite(y).all())
+        x2 = x.clone()
+        x2[1, 3, 5, 7] = float("nan")
+        slot = torch.zeros(1, device="cuda")
+        assert lib.vg_absmax(x2.data_ptr(), x2.numel(), slot.data_ptr(), None) == 0
+        assert bool(torch.isnan(slot).all())
+        assert bool(torch.isnan(H.conv5x5_fwd(x2, w, None, 2)).any())
+        # the bound is exact, order-independent and accumulates over calls
+        slot.zero_()
+        assert lib.vg_absmax(x.data_ptr(), x.numel(), slot.data_ptr(), None) == 0
+        assert float(slot) == float(x.abs().max())
+        assert lib.vg_absmax(w.data_ptr(), w.numel(), slot.data_ptr(), None) == 0
+        assert float(slot) == float(x.abs().max())
+    finally:
+        H.CONV_ARITH = prev_arith
+
+
 # ------------------------------------------------------------------ Conv <-> BatchNorm fusion (SURVEY K5)
 @pytest.mark.parametrize("transposed,B,Cin,Cout,Hs,Ws,act", [
     (False, 4, 32, 128, 16, 16, "lrelu"), (False, 3, 48, 70, 14, 10, "relu"), (False, 64, 128, 256, 16, 16, "lrelu"),
@@ -829,7 +930,7 @@ def test_convT_thin_split(H, B, Cout, Hs, Ws, act):
     lib = __import__("disentangle_mlp_amd._lib", fromlist=["load"]).load()
     assert lib.vg_convT5x5_s1_thin_bf16split_ok(32, Hs, Ws, Cout) == 1
     assert lib.vg_convT5x5_s1_thin_bf16split_ok(16, Hs, Ws, Cout) == 0 and lib.vg_convT5x5_s1_thin_bf16split_ok(32, Hs, 24, Cout) == 0
-    tol = CONV_TOL if os.environ.get("VG_CONV_ARITH", "bf16x6") != "bf16x3" else 2e-5
+    tol = CONV_TOL if os.environ.get("VG_CONV_ARITH", "fp16x3") != "bf16x3" else 2e-5
     if act is None:
         ref = O.convT5x5(x, w, bias, 1)
         assert_close(H.convT5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), 1), ref, tol, "thin convT")
@@ -856,7 +957,7 @@ def test_conv_thin_split(H, B, Cin, Cout, Hs, Ws, stride):
     lib = __import__("disentangle_mlp_amd._lib", fromlist=["load"]).load()
     assert lib.vg_conv5x5_thin_bf16split_ok(Cin, Hs, Ws, Cout, stride) == 1
     assert lib.vg_conv5x5_thin_bf16split_ok(4, Hs, Ws, Cout, stride) == 0
-    tol = CONV_TOL if os.environ.get("VG_CONV_ARITH", "bf16x6") != "bf16x3" else 2e-5
+    tol = CONV_TOL if os.environ.get("VG_CONV_ARITH", "fp16x3") != "bf16x3" else 2e-5
     ref = O.conv5x5(x, w, bias, stride)
     y, stats = H.conv5x5_fwd(x.cuda(), w.cuda(), bias.cuda(), stride, want_stats=True)
     assert_close(y, ref, tol, "thin conv")
@@ -881,7 +982,7 @@ def test_conv_thin_wgrad_split(H, B, Cin, Cout, Hs, Ws, stride):
     OH, OW = (Hs - 1) // stride + 1, (Ws - 1) // stride + 1
     gy = torch.randn(B, Cout, OH, OW, generator=g)
     lib = __import__("disentangle_mlp_amd._lib", fromlist=["load"]).load()
-    planes = 2 if os.environ.get("VG_CONV_ARITH", "bf16x6") == "bf16x3" else 3
+    planes = 2 if os.environ.get("VG_CONV_ARITH", "fp16x3") == "bf16x3" else 3
     assert lib.vg_conv5x5_thin_wgrad_bf16split_workspace_bytes(B, Cin, Hs, Ws, Cout, stride, planes) > 0
     assert lib.vg_conv5x5_thin_wgrad_bf16split_workspace_bytes(B, 4, Hs, Ws, Cout, stride, planes) == 0
     tol = CONV_TOL if planes == 3 else 2e-5
@@ -905,7 +1006,7 @@ def test_conv_thin_wgrad_with_affine_on_the_wide_operand(H, B, Hs, Ws, act):
     aff = (scale.cuda(), shift.cuda(), act)
     gw = H.conv5x5_wgrad(gy.cuda(), x.cuda(), 1, in_affine=aff, affine_on_gy=True)
     assert gw.shape == (32, 3, 5, 5)
-    tol = CONV_TOL if os.environ.get("VG_CONV_ARITH", "bf16x6") != "bf16x3" else 2e-5
+    tol = CONV_TOL if os.environ.get("VG_CONV_ARITH", "fp16x3") != "bf16x3" else 2e-5
     if B <= 8:
         xa = x.double() * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
         xa = xa.clamp(min=0) if act == 1 else torch.where(xa > 0, xa, 0.2 * xa)
