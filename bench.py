@@ -305,16 +305,6 @@ def main():
     host_ms = timed_steps.host_ms
     dom_ms = ops.stop_timing().get(dominant, []) if not graphed else []
     out = {k: v.clone() for k, v in out.items()}
-    # what regime the last timed step ran in: mean D(x), and how much of the gradient that D sends back into the decoder
-    # through the generated batch is exactly zero (one probed -- eager -- iteration right after the timed region)
-    regime = {"D_x_mean_last_timed_step": round(float(out["D_x_sum"]) / B, 6),
-              "iterations_since_initial_weights": args.warmup + args.steps}
-    def _probe(name, gten):
-        regime["fake_path_gy_zero_fraction"] = round(float((gten == 0).float().mean()), 6)
-        regime["fake_path_gy_absmax"] = float(gten.abs().max())
-    tr.probe = _probe
-    one_step()
-    tr.probe = None
     comm = None
     if world > 1:
         ranks = torch.ones(1, device=dev)
@@ -326,6 +316,16 @@ def main():
                 "backend": dist.get_backend()}
     for f in flats:
         f.time_finish = False
+    # what regime the last timed step ran in: mean D(x), and how much of the gradient that D sends back into the decoder
+    # through the generated batch is exactly zero (one probed -- eager -- iteration right after the timed region)
+    regime = {"D_x_mean_last_timed_step": round(float(out["D_x_sum"]) / B, 6),
+              "iterations_since_initial_weights": args.warmup + args.steps}
+    def _probe(name, gten):
+        regime["fake_path_gy_zero_fraction"] = round(float((gten == 0).float().mean()), 6)
+        regime["fake_path_gy_absmax"] = float(gten.abs().max())
+    tr.probe = _probe
+    one_step()
+    tr.probe = None
 
     # ---- launches inside a replayed graph cannot be bracketed by events: the dominant kernel's K x n launches are timed
     # in an eager leg of the same K iterations right after the timed region (same process, same kernels, same inputs)
