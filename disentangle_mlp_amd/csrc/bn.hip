@@ -605,6 +605,7 @@ __global__ __launch_bounds__(NT) void stats_partial_kernel(const float* __restri
   }
 }
 
+constexpr int AA_U = 4;
 // y = act(x * scale[c] + shift[c]): the normalise pass with given coefficients (layers whose consumer cannot apply
 // them while it loads)
 // hw4_shift >= 0: H*W/4 is a power of two (every layer of the reference) -- the channel is a shift and a 32-bit remainder;
@@ -613,21 +614,33 @@ __global__ __launch_bounds__(NT) void affine_act_kernel(const float* __restrict_
                                                         const float* __restrict__ shift, float* __restrict__ y, int C,
                                                         int HW, size_t n4, int act, int hw4_shift,
                                                         unsigned* __restrict__ y_amax) {
-  const size_t i0 = (size_t)blockIdx.x * NT + threadIdx.x;
-  const size_t i = i0 < n4 ? i0 : n4 - 1;                   // the tail threads redo the last unit (they take part in the maximum)
-  const size_t e = 4 * i;
-  // HW % 4 == 0: the four elements share a channel
-  const int c = hw4_shift >= 0 ? (int)((unsigned)(i >> hw4_shift) % (unsigned)C) : (int)((e / HW) % C);
-  const float sc = scale[c], sh = shift[c];
-  const float4 v = *reinterpret_cast<const float4*>(x + e);
-  float4 o;
-  o.x = act_fwd(fmaf(v.x, sc, sh), act);
-  o.y = act_fwd(fmaf(v.y, sc, sh), act);
-  o.z = act_fwd(fmaf(v.z, sc, sh), act);
-  o.w = act_fwd(fmaf(v.w, sc, sh), act);
-  if (i0 < n4) *reinterpret_cast<float4*>(y + e) = o;
-  if (y_amax)      // max |y| for an fp16-plane consumer (common.hpp block_amax_atomic)
-    block_amax_atomic<NT>(max(max(abs_bits(o.x), abs_bits(o.y)), max(abs_bits(o.z), abs_bits(o.w))), y_amax);
+  // AA_U units of 16 bytes per thread, a workgroup's units contiguous per round (loads of all rounds in flight together)
+  const size_t base = (size_t)blockIdx.x * (NT * AA_U) + threadIdx.x;
+  float4 v[AA_U];
+  float sc[AA_U], sh[AA_U];
+#pragma unroll
+  for (int u = 0; u < AA_U; ++u) {
+    const size_t i0 = base + (size_t)u * NT;
+    const size_t i = i0 < n4 ? i0 : n4 - 1;                 // tail threads redo the last unit (they take part in the maximum)
+    // HW % 4 == 0: the four elements share a channel
+    const int c = hw4_shift >= 0 ? (int)((unsigned)(i >> hw4_shift) % (unsigned)C) : (int)(((4 * i) / HW) % C);
+    sc[u] = scale[c];
+    sh[u] = shift[c];
+    v[u] = *reinterpret_cast<const float4*>(x + 4 * i);
+  }
+  unsigned am = 0;
+#pragma unroll
+  for (int u = 0; u < AA_U; ++u) {
+    const size_t i0 = base + (size_t)u * NT;
+    float4 o;
+    o.x = act_fwd(fmaf(v[u].x, sc[u], sh[u]), act);
+    o.y = act_fwd(fmaf(v[u].y, sc[u], sh[u]), act);
+    o.z = act_fwd(fmaf(v[u].z, sc[u], sh[u]), act);
+    o.w = act_fwd(fmaf(v[u].w, sc[u], sh[u]), act);
+    if (i0 < n4) *reinterpret_cast<float4*>(y + 4 * i0) = o;
+    am = max(max(am, abs_bits(o.x)), max(max(abs_bits(o.y), abs_bits(o.z)), abs_bits(o.w)));
+  }
+  if (y_amax) block_amax_atomic<NT>(am, y_amax);      // max |y| for an fp16-plane consumer (common.hpp)
 }
 
 // the same for H*W not a multiple of 4 (odd image sizes): one element per lane
@@ -721,7 +734,7 @@ extern "C" int vg_affine_act(const float* x, const float* scale, const float* sh
     while ((1 << sh) < hw4) ++sh;
     if ((n4 >> sh) > 0xffffffffULL) sh = -1;
   }
-  hipLaunchKernelGGL(affine_act_kernel, dim3((unsigned)((n4 + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, x, scale,
+  hipLaunchKernelGGL(affine_act_kernel, dim3((unsigned)((n4 + NT * AA_U - 1) / (NT * AA_U))), dim3(NT), 0, (hipStream_t)stream, x, scale,
                      shift, y, C, HW, n4, act, sh, (unsigned*)y_amax);
   VG_CHECK_LAUNCH();
   return 0;

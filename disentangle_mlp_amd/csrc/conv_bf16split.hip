@@ -30,7 +30,7 @@ namespace {
 
 enum { X_FWD = 0, X_TR = 1 };
 constexpr int XNT = 256;
-constexpr int VG_PACK_SPARE = 3;   // zero steps behind a pack (the ring kernel's DMA runs three steps ahead)
+constexpr int VG_PACK_SPARE = 6;   // zero steps behind a pack (the ring kernel's DMA runs up to six steps ahead: RING_MAX_SLOTS)
 
 // 16-byte units per patch row (FWD stride 2: per column parity).  Chosen so that the patch rows a
 // 32-pixel fragment spans start on disjoint groups of 16 units (= 256 B, one LDS bank row):

@@ -27,7 +27,21 @@ namespace {
 
 enum { R_FWD = 0, R_TR = 1 };
 constexpr int RNT = 512;          // 8 wavefronts
-constexpr int NSLOT = 3;
+// Depth of the filter ring: DMA(k + NSLOT) is issued in body k.  3 slots.  With fp16 planes a step holds half the MFMAs
+// of a bf16x6 step and three steps of run-ahead looked marginal against the L2 -> LDS latency, so round 4 timed 4, 5 and
+// 6 slots (-DVG_RING_SLOTS=n, fp16 planes only): 169.6-173.0 us against 169.9-172.0 on the dominant layer, no
+// difference (profiles/r04_logs/r4_slots.log) -- the wavefronts do not wait for the DMA.
+#ifndef VG_RING_SLOTS
+#define VG_RING_SLOTS 3
+#endif
+constexpr int ring_slots(bool f16, int slotu, int patchu) {
+  if (!f16) return 3;
+  int n = VG_RING_SLOTS;
+  while (n > 3 && (n * slotu + patchu + 1) * 16 > 160 * 1024) --n;
+  return n;
+}
+constexpr int RING_MAX_SLOTS = 6;      // <= VG_PACK_SPARE of conv_bf16split.hip: the run-ahead past the last step reads zeros
+static_assert(VG_RING_SLOTS >= 3 && VG_RING_SLOTS <= RING_MAX_SLOTS, "ring depth");
 
 // 16-byte units per patch row; same bank rules as conv_bf16split.hip (fragments of 2 rows x 16 pixels need the
 // two rows 0 (mod 16) units apart, 4 rows x 8 pixels 8 (mod 16))
@@ -59,6 +73,7 @@ struct RCfg {
   static constexpr int BUFU = (MODE == R_FWD) ? NP * IMGU : NP * 2 * IMGU;
   static constexpr int PATCHU = 2 * BUFU;
   static constexpr int SLOTU = NP * 2 * TN;                            // one K step of the filter: [plane][kb][cout]
+  static constexpr int NSLOT = ring_slots(F16_, SLOTU, PATCHU);
   static constexpr int RINGU = NSLOT * SLOTU;
   static constexpr int LDSU = RINGU + PATCHU + 1;                      // + one dummy unit for masked staging writes
   static constexpr int DMA_TOTAL = SLOTU / 64;                         // 1 KiB DMA instructions per step
@@ -109,19 +124,23 @@ __host__ __device__ constexpr int tr_taps_before(int R, int SS) {
   return n;
 }
 
-__device__ const float k_unit_scale = 1.f, k_zero_shift = 0.f;      // the "no fusion" input coefficients
-
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <class C, int R, int SS>
+// AFF: the input is read through a producer's BatchNorm + activation (RArgs::in_scale); a template parameter, so that
+// plain launches (every data gradient) carry none of its arithmetic and the coefficients of the others come by scalar
+// loads from the kernel argument itself.  (Round 3 selected between in_scale and a __device__ constant at run time: the
+// compiler could not tell the address space, loaded the 16 coefficients of a unit with flat_load and drained vmcnt(0)
+// -- the whole filter ring -- in front of every unit's arithmetic: ~2000 cycles per staging event.)
+template <class C, int R, int SS, bool AFF>
 __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, int split) {
   constexpr int MODE = C::MODE, S = C::S, NB = C::NB, TH = C::TH, TW = C::TW, PH = C::PH, PW = C::PW;
   constexpr int COLS = C::COLS, ROWU = C::ROWU, IMGU = C::IMGU, NQ = C::NQ, FC = C::FC, FP = C::FP, NP = C::NP;
   constexpr int NTMAX = C::NTMAX, BUFU = C::BUFU, SLOTU = C::SLOTU, NDMA = C::NDMA, NL = C::NL, TN = C::TN;
+  constexpr int NSLOT = C::NSLOT;
   constexpr bool F16 = C::F16;
   constexpr int NTH = (MODE == R_FWD) ? 5 : (5 - R + 1) / 2;     // taps along h / w in this class
   constexpr int NTW = (MODE == R_FWD) ? 5 : (5 - SS + 1) / 2;
@@ -144,6 +163,7 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
 #endif
   constexpr bool STG = VG_RING_STAGGER != 0;
   const bool early = STG && wid >= 4;                             // wave-uniform: meets each barrier half a body late
+  const bool late = wid >= 4;      // wave-uniform: the second-dispatched half (timing experiments VG_RING_PLACE = 1, 2)
   const int kb = lane >> 5, l32 = lane & 31;
   const int wc = wid % C::WC, wp = wid / C::WC;
   // XCD-aware placement (conv_igemm.hip): the cout tiles of one pixel tile share an XCD
@@ -204,10 +224,7 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
 
   float preg[NQ][8];
   int staged_c0 = 0;      // first channel of the units in preg (wave-uniform)
-  const int aff_mask = A.in_scale ? -1 : 0;
-  const float* aff_scale = A.in_scale ? A.in_scale : &k_unit_scale;
-  const float* aff_shift = A.in_scale ? A.in_shift : &k_zero_shift;
-  const float aff_slope = !A.in_scale || A.in_act == VG_ACT_NONE ? 1.f : (A.in_act == VG_ACT_RELU ? 0.f : 0.2f);
+  const float aff_slope = A.in_act == VG_ACT_NONE ? 1.f : (A.in_act == VG_ACT_RELU ? 0.f : 0.2f);
   // fp16 planes: the activated input times an exact power of two (wave-uniform, from the caller's bound on max |input|)
   float x_scale = 1.f, x_unscale = 1.f;
   if constexpr (F16) {
@@ -234,14 +251,15 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
     const Unit u = unit_of(q);
     f32x4 pl[NP];
     float vv[8];
-    // BatchNorm + activation of the producing layer, on load -- branch-free (a branch here keeps hipcc from unrolling
-    // the K steps, and the fragment registers then go to scratch): without a fusion the coefficients are 1 / 0 /
-    // slope 1 read from element 0 of constant arrays.  Scalar loads: a unit's channels are wave-uniform.
-    const int cb = aff_mask & (staged_c0 + ((MODE == R_FWD) ? 0 : (q & 1) * 8));
+    // BatchNorm + activation of the producing layer, on load.  Scalar loads: a unit's channels are wave-uniform.
+    const int cb = __builtin_amdgcn_readfirstlane(staged_c0 + ((MODE == R_FWD) ? 0 : (q & 1) * 8));
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float v = fmaf(preg[q][j], aff_scale[cb + (aff_mask & j)], aff_shift[cb + (aff_mask & j)]);
-      v = act_slope(v, aff_slope);                    // slope 1: identity, 0: ReLU, 0.2: LeakyReLU
+      float v = preg[q][j];
+      if constexpr (AFF) {
+        v = fmaf(v, A.in_scale[cb + j], A.in_shift[cb + j]);
+        v = act_slope(v, aff_slope);                  // slope 1: identity, 0: ReLU, 0.2: LeakyReLU
+      }
       v = u.ok ? v : 0.f;                             // zero padding pads the ACTIVATED tensor
       vv[j] = F16 ? v * x_scale : v;
     }
@@ -363,9 +381,8 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
   constexpr int RS = (NMF / NRD) > 0 ? (NMF / NRD) : 1;
   // ---- prologue: first patch buffer, ring slots 0..2, fragments of step 0
   dma_ptr += (size_t)st0 * wstep;
-  dma_next(0);
-  dma_next(1);
-  dma_next(2);
+#pragma unroll
+  for (int i = 0; i < NSLOT; ++i) dma_next(i);
   stage_load(c_begin * 16);
   stage_store(0);
   wait_vmcnt<0>();
@@ -374,6 +391,14 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
   for (int j = 0; j < NRD; ++j) read_one(0, j, 0, patch_off(0, 0));
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
+#ifdef VG_RING_STAMP      // diagnostic build (scripts/ring_stamps.py): where a wavefront's cycles go, summed over its steps --
+  // [body top .. barrier passed], [.. last MFMA issued], [.. waits done].  s_memtime answers asynchronously (lgkmcnt): the
+  // three stamps of a body are read after the body's own lgkmcnt(0); the sums leave through the statistics buffer.
+  unsigned long long tk_a = 0, tk_b = 0, tk_c = 0, tk_d = 0, sum_bar = 0, sum_mf = 0, sum_tail = 0, sum_all = 0;
+  unsigned long long tm[NMF < 12 ? NMF : 12];      // the issue times of the LAST step's first 12 MFMAs (overwritten every step)
+#pragma unroll
+  for (int i = 0; i < NMF && i < 12; ++i) tm[i] = 0;
+#endif
   int slot = 0;        // ring slot of the current step
   for (int ch = c_begin; ch < c_end; ++ch) {
     const int pcur = (MODE == R_TR) ? ((ch - c_begin) & 1) * BUFU : 0;
@@ -390,7 +415,13 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
       const int wbuf = (MODE == R_FWD) ? (s == 4 ? BUFU : 0) : pnxt;
       // B_k: slot (k+1)%3 and the patch writes of body k-1 are visible.  Staggered build: the second-dispatched half of
       // the wavefronts (4-7: the SIMD partners of 0-3) meets the same barrier in the MIDDLE of its body, see below.
+#ifdef VG_RING_STAMP
+      asm volatile("s_memtime %0" : "=s"(tk_a));
+#endif
       if (!(abl & 2) && !early) __builtin_amdgcn_s_barrier();
+#ifdef VG_RING_STAMP
+      asm volatile("s_memtime %0" : "=s"(tk_b));
+#endif
       __builtin_amdgcn_sched_barrier(0);
       const int nslot = (slot == NSLOT - 1) ? 0 : slot + 1;
       const int so = nslot * SLOTU;
@@ -438,15 +469,40 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
           for (int q = H2N; q < NQ; ++q) split_unit(q, wbuf);
         }
       } else {
+      // Placement of the step's vector-memory instructions (filter DMA, a staging event's loads behind it) and of a
+      // written unit's split: behind MFMA 0 and between the later MFMAs, the same in all eight wavefronts.  Round 4 timed
+      // two other placements with per-MFMA s_memtime stamps (scripts/ring_stamps.py, profiles/r04_logs/r4_stamps*.log):
+      // the DMA half a body later in wavefronts 4-7 (VG_RING_PLACE=1), and the whole memory block in front of the MFMAs
+      // in wavefronts 4-7 / behind them in 0-3 (VG_RING_PLACE=2).  Both within 2 % of this one (154.7-157.5 us against
+      // 159.5-163 on the dominant layer): the two wavefronts of a SIMD do not interleave their MFMAs whatever the
+      // placement -- the older one wins every arbitration while it has an instruction ready and runs its twelve first --
+      // and an LDS-DMA instruction holds its in-order wavefront 70-190 cycles wherever it stands.
+#ifndef VG_RING_PLACE
+#define VG_RING_PLACE 0
+#endif
+      auto mem_block = [&]() {
+        if (!(abl & 1)) dma_next(slot);                    // step k+NSLOT into the slot read during body k-1
+        if (ld && !(abl & 4)) {
+          if constexpr (MODE == R_FWD) stage_load(ch * 16 + (s == 0 ? 8 : 16));
+          else stage_load((ch + 1) * 16);
+        }
+        if (VG_RING_PLACE == 2 && wr && !(abl & 4)) {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) split_unit(q, wbuf);
+        }
+      };
+      if (VG_RING_PLACE == 2 && late) {
+        mem_block();
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int i = 0; i < NMF; ++i) {
         if (!(abl & 64)) mfma_one(cur, i);
-        if (i == 0) {
-          if (!(abl & 1)) dma_next(slot);                  // step k+3 into the slot read during body k-1
-          if (ld && !(abl & 4)) {
-            if constexpr (MODE == R_FWD) stage_load(ch * 16 + (s == 0 ? 8 : 16));
-            else stage_load((ch + 1) * 16);
-          }
+#ifdef VG_RING_STAMP
+        if (i < 12) asm volatile("s_memtime %0" : "=s"(tm[i]));
+#endif
+        if (VG_RING_PLACE < 2 && (i == 0 || i == NMF / 2)) {
+          if ((i != 0) == (VG_RING_PLACE == 1 && late)) mem_block();
           __builtin_amdgcn_sched_barrier(0);
         }
         if (i % RS == RS - 1 && i / RS < NRD) {
@@ -454,7 +510,7 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
           __builtin_amdgcn_sched_barrier(0);
         }
         // a written unit's split (VALU) + ds_writes go between the later MFMAs
-        if (wr && !(abl & 4) && i >= NMF / 2 && (i - NMF / 2) < NQ) {
+        if (VG_RING_PLACE < 2 && wr && !(abl & 4) && i >= NMF / 2 && (i - NMF / 2) < NQ) {
           split_unit(i - NMF / 2, wbuf);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -470,19 +526,44 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
           asm volatile("" ::"v"(d));
         }
       }
-      if (wr && !(abl & 4)) {
+      if (VG_RING_PLACE < 2 && wr && !(abl & 4)) {
 #pragma unroll
         for (int q = NMF - NMF / 2; q < NQ; ++q) split_unit(q, wbuf);
+      }
+      if (VG_RING_PLACE == 2 && !late) {
+        __builtin_amdgcn_sched_barrier(0);
+        mem_block();
       }
       }
       // DMA(k+2) has landed (DMA(k+3), and a staging event's loads for two bodies, stay in flight);
       // this wavefront's reads of step k+1 and its patch writes are done
       __builtin_amdgcn_sched_barrier(0);
-      const bool ldw = (MODE == R_FWD) ? (s == 0 || s == 1 || s == 13 || s == 14) : (s == 0 || s == 1);
+#ifdef VG_RING_STAMP
+      asm volatile("s_memtime %0" : "=s"(tk_c));
+#endif
+      // In flight behind DMA(k+2), in issue order: DMA(k+3) .. DMA(k+NSLOT), and a staging event's loads for the NSLOT - 1
+      // bodies from the one that issued them (they follow that body's DMA; hipcc itself waits for them where the
+      // registers are used)
+      const bool ldw = (MODE == R_FWD) ? ((s >= 0 && s < NSLOT - 1) || (s >= 13 && s < 13 + NSLOT - 1)) : (s >= 0 && s < NSLOT - 1);
       if (abl & (8 | 4 | 1)) {                                      // ablations change what is in flight: drain or skip
         if (!(abl & 8)) wait_vmcnt<0>();
-      } else if (ldw) wait_vmcnt<NDMA + NL>(); else wait_vmcnt<NDMA>();
+      } else if (ldw) wait_vmcnt<(NSLOT - 2) * NDMA + NL>(); else wait_vmcnt<(NSLOT - 2) * NDMA>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef VG_RING_STAMP
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk_d), "+s"(tk_a), "+s"(tk_b), "+s"(tk_c));
+      // the per-MFMA stamps are pinned until here too: s_memtime answers asynchronously, and a register the compiler
+      // had meanwhile given to something else (an address) would be overwritten when the answer lands
+      static_assert(NMF == 12 || NMF == 6 || NMF == 24, "stamp pinning below");
+      if constexpr (NMF >= 12)
+        asm volatile("" : "+s"(tm[0]), "+s"(tm[1]), "+s"(tm[2]), "+s"(tm[3]), "+s"(tm[4]), "+s"(tm[5]), "+s"(tm[6]), "+s"(tm[7]),
+                     "+s"(tm[8]), "+s"(tm[9]), "+s"(tm[10]), "+s"(tm[11]));
+      else
+        asm volatile("" : "+s"(tm[0]), "+s"(tm[1]), "+s"(tm[2]), "+s"(tm[3]), "+s"(tm[4]), "+s"(tm[5]));
+      sum_bar += tk_b - tk_a;
+      sum_mf += tk_c - tk_b;
+      sum_tail += tk_d - tk_c;
+      sum_all += 1;
+#endif
       __builtin_amdgcn_sched_barrier(0);
       slot = nslot;
     }
@@ -508,8 +589,20 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
   }
 
   const int YH = A.YH, YW = A.YW;
+#ifdef VG_RING_STAMP
+  if (A.stats && lane == 0 && bid < 64) {
+    unsigned long long* o = (unsigned long long*)A.stats + (size_t)(bid * 8 + wid) * 4;
+    o[0] = sum_bar; o[1] = sum_mf; o[2] = sum_tail; o[3] = sum_all;
+    unsigned long long* o2 = (unsigned long long*)A.stats + 64 * 8 * 4 + (size_t)(bid * 8 + wid) * 16;
+    o2[0] = tk_a; o2[1] = tk_b; o2[2] = tk_c; o2[3] = tk_d;
+#pragma unroll
+    for (int i = 0; i < NMF && i < 12; ++i) o2[4 + i] = tm[i];
+  }
+  if (false) {
+#else
   // ---- optional: per-channel sums of the output for the next BatchNorm (ksplit == 1 only: the host says so)
   if (A.stats) {
+#endif
     bool pokf[FP];
 #pragma unroll
     for (int f = 0; f < FP; ++f) {
@@ -573,13 +666,13 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
   }
 }
 
-template <class C>
+template <class C, bool AFF>
 __global__ __launch_bounds__(RNT, 2) void conv5x5_ring_kernel(RArgs A) {
   __shared__ f32x4 lds[C::LDSU];     // ONE array: [filter ring 3 slots][patch buffers][dummy]
   int bid = blockIdx.x;
   if constexpr (C::NCLS == 1) {
     const int split = bid / A.blocks_per_cls;
-    ring_body<C, 0, 0>(A, lds, bid - split * A.blocks_per_cls, split);
+    ring_body<C, 0, 0, AFF>(A, lds, bid - split * A.blocks_per_cls, split);
   } else {
     // [class][split][tile]; class 0 (3x3 taps) first: the longest blocks start earliest
     const int per = A.blocks_per_cls;
@@ -589,10 +682,10 @@ __global__ __launch_bounds__(RNT, 2) void conv5x5_ring_kernel(RArgs A) {
     const int split = bid / per;
     bid -= split * per;
     switch (cls) {
-      case 0: ring_body<C, 0, 0>(A, lds, bid, split); break;
-      case 1: ring_body<C, 0, 1>(A, lds, bid, split); break;
-      case 2: ring_body<C, 1, 0>(A, lds, bid, split); break;
-      default: ring_body<C, 1, 1>(A, lds, bid, split); break;
+      case 0: ring_body<C, 0, 0, AFF>(A, lds, bid, split); break;
+      case 1: ring_body<C, 0, 1, AFF>(A, lds, bid, split); break;
+      case 2: ring_body<C, 1, 0, AFF>(A, lds, bid, split); break;
+      default: ring_body<C, 1, 1, AFF>(A, lds, bid, split); break;
     }
   }
 }
@@ -614,7 +707,7 @@ int launch_ring(const float* x, const bf16x8* w, const float* bias, float* y, in
   A.stats = (ksplit == 1) ? fu.stats : nullptr;
   A.in_amax = fu.in_amax;
   // the pack's trailer (conv_bf16split.hip, pack kernel): behind the steps and the spare steps
-  A.w_unscale = (const float*)(w + (size_t)(Cin / 16 * 25 + 3) * 2 * C::NP * ((Cout + 127) & ~127));
+  A.w_unscale = (const float*)(w + (size_t)(Cin / 16 * 25 + RING_MAX_SLOTS) * 2 * C::NP * ((Cout + 127) & ~127));
   A.B = B; A.Cin = Cin; A.XH = XH; A.XW = XW; A.Cout = Cout; A.CoutP = (Cout + 127) & ~127;
   int tsh, tsw;
   if (C::MODE == R_FWD) {
@@ -634,7 +727,8 @@ int launch_ring(const float* x, const bf16x8* w, const float* bias, float* y, in
   A.cps = cdiv(Cin / 16, ksplit);
   A.ysplit = (size_t)B * Cout * A.YH * A.YW;
   if (ksplit > 1) A.y = slabs;
-  hipLaunchKernelGGL(conv5x5_ring_kernel<C>, dim3((unsigned)grid), dim3(RNT), 0, st, A);
+  if (A.in_scale) hipLaunchKernelGGL((conv5x5_ring_kernel<C, true>), dim3((unsigned)grid), dim3(RNT), 0, st, A);
+  else hipLaunchKernelGGL((conv5x5_ring_kernel<C, false>), dim3((unsigned)grid), dim3(RNT), 0, st, A);
   VG_CHECK_LAUNCH();
   if (ksplit > 1) {
     if (A.ysplit > 0x7fffffffUL) return VG_ERR_BAD_ARG;

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from disentangle_mlp_amd import ops, _lib
 lib = _lib.use_tuning().__enter__()      # the vg_debug_* knobs live in the tuning build only
-ops.CONV_ARITH = sys.argv[1] if len(sys.argv) > 1 else "bf16x6"
+ops.CONV_ARITH = sys.argv[1] if len(sys.argv) > 1 else "fp16x3"
 B = 128
 FWD = [(32, 128, 64), (64, 128, 32), (128, 256, 32), (128, 256, 16), (256, 256, 16)]      # Cin, Cout, H (stride 2)
 TR = [(256, 256, 8), (256, 128, 16), (256, 128, 8), (128, 64, 16), (128, 32, 32)]

@@ -1072,6 +1072,25 @@ def test_dot_sigmoid_bce(H, B, K, label, dev_label):
     # saturated rows: BCE's gradient w.r.t. p is clamped at 1e-12 in p (1 - p), the chain through the sigmoid gives
     # (p - t) p (1 - p) / max(p (1 - p), 1e-12): bounded by |p - t| / B
     assert float(gfeat.cpu()[~ok].abs().max() if (~ok).any() else 0.0) <= 0.75 * float(w.abs().max()) / B * 1.001
+    # loss, gw, gb: ALWAYS against the oracle (round 3 compared them only when no row saturated, and rows 0 / 1 always do).
+    # (a) the unsaturated rows alone through the same kernels, same divisor B, against the fp64 oracle of those rows;
+    fo, wo, bo = feat[ok].double().requires_grad_(), w.double().requires_grad_(), bias.double().requires_grad_()
+    po = torch.sigmoid(fo @ wo.t() + bo).squeeze(1)
+    lo_ref = torch.nn.functional.binary_cross_entropy(po, lab[ok], reduction="sum") / B
+    (0.75 * lo_ref).backward()
+    p_o, loss_o, dlogit_o = H.dot_sigmoid_bce_fwd(feat[ok].cuda().contiguous(), w.cuda(), bias.cuda(), target, divisor=B)
+    assert abs(float(loss_o) - float(lo_ref)) <= 2e-5 * abs(float(lo_ref)), (float(loss_o), float(lo_ref))
+    gfeat_o, gw_o, gb_o = H.dot_sigmoid_bce_bwd(dlogit_o, gl, feat[ok].cuda().contiguous(), w.cuda())
+    assert_close(gw_o.cpu(), wo.grad, 1e-5, "gw (unsaturated rows)")
+    assert_close(gb_o.cpu(), bo.grad, 1e-5, "gb (unsaturated rows)")
+    assert_close(gfeat_o.cpu(), fo.grad, 1e-5, "gfeat (unsaturated rows alone)")
+    # (b) the whole batch = (a) + what the saturated rows add through the kernel's own clamped dlogit (bounded above)
+    dl = dlogit.double().cpu()
+    assert float(dl[~ok].abs().max() if (~ok).any() else 0.0) <= 1.001 / B
+    gw_full = wo.grad + 0.75 * (dl[~ok].unsqueeze(1) * feat[~ok].double()).sum(0, keepdim=True)
+    gb_full = bo.grad + 0.75 * dl[~ok].sum()
+    assert_close(gw.cpu(), gw_full, 1e-5, "gw (whole batch)")
+    assert_close(gb.cpu(), gb_full.reshape(gb.shape), 1e-5, "gb (whole batch)")
     if bool(ok.all()):
         assert_close(gw.cpu(), wd.grad, 1e-5, "gw")
         assert_close(gb.cpu(), bd.grad, 1e-5, "gb")
