@@ -465,6 +465,26 @@ def test_vae_and_gan_captured_steps_equal_eager(T):
 
 
 # ------------------------------------------------------------------ parity AWAY from the initial weights
+def _tap_unit_signs(mods, store):
+    """Forward hooks recording, per call, the signs of a layer's B x 2048 (or B x 16384) post-activation units and a
+    signature of the call (the mean of its output: which batch went through)."""
+    return [m.register_forward_hook(lambda mod, inp, o, i=i: store.append((i, float(o.detach().double().mean()),
+                                                                           (o.detach() > 0).flatten().cpu())))
+            for i, m in enumerate(mods)]
+
+
+def _count_flips(a, b):
+    """Units whose sign differs between two runs of the same iteration; calls matched per layer by their signature (the
+    two implementations do not visit D's three batches in the same order)."""
+    flips, b = 0, list(b)
+    for (i, sa, ma) in a:
+        j = min((k for k in range(len(b)) if b[k][0] == i and b[k][2].numel() == ma.numel()),
+                key=lambda k: abs(b[k][1] - sa))
+        flips += int((ma != b[j][2]).sum())
+        b.pop(j)
+    return flips
+
+
 def _trained_oracle(k_iters, batch, seed=31, lr=3e-4):
     """The oracle trained for k iterations on the host (fp32, the reference's schedule).  lr 3e-4 rather than the
     reference's 1e-3: on synthetic images D saturates to D(x) = 1.0f within three lr = 1e-3 iterations (fp32
@@ -485,7 +505,8 @@ def _trained_oracle(k_iters, batch, seed=31, lr=3e-4):
     return eg, d, oeg, od, data, g
 
 
-def test_gradients_at_trained_weights_vs_oracle(T):
+@pytest.mark.parametrize("batch", [16, 128])
+def test_gradients_at_trained_weights_vs_oracle(T, batch):
     """`test_betavaegan_gradients_vs_live_oracle` differentiates at the initial weights only.  Here the ORACLE
     trains k = 2 iterations on the host; its checkpoint (both models + both Adam states, the reference's dict)
     is loaded into the HIP trainer, and ONE lr = 0 iteration on a fresh batch is compared at those trained
@@ -494,8 +515,9 @@ def test_gradients_at_trained_weights_vs_oracle(T):
     same inputs) against that fp64 run) -- ReLU units whose pre-activation rounds to the other side of zero move
     a gradient tensor by ~1e-3 each in either fp32 evaluation.  Phase 3 is thus checked tensor by tensor away from
     init (conftest.GRADNORM_TOL['EG3'] = 0.5 in the golden-vector test is only a chaos bound)."""
+    # batch 128: the benchmarked configuration itself, away from the initial weights (round 4; ~2 min of host time for
+    # the oracle's five iterations)
     import copy
-    batch = 16
     eg, d, oeg, od, data, g = _trained_oracle(2, batch)
     ck = {"epoch": 1, "encoder_decoder_model": eg.state_dict(),
           "discriminator_model": {"module." + k: v for k, v in d.state_dict().items()},
@@ -519,12 +541,23 @@ def test_gradients_at_trained_weights_vs_oracle(T):
     ref32_l = osteps.betavaegan_step(eg32, d32, o32[0], o32[1], x, no, e2, e3, beta=25.0,
                                      grad_hook=lambda ph, net: ref32_g.__setitem__(
                                          ph, {k: p.grad.detach().double().clone() for k, p in net.named_parameters()}))
+    # signs of the units behind the big Linear layers, in the fp64 oracle and in the build: a unit whose pre-activation
+    # lands on the other side of zero moves every gradient behind it by ~0.8 / sqrt(units) (1.6e-3 at batch 128) in ANY
+    # fp32 evaluation -- the reference's own (e32 below) included
+    signs64, signs_hip = [], []
+    taps = _tap_unit_signs((eg64.x_to_mu[2], eg64.x_to_logvar[2], eg64.preprocess[2], d64.lth_features[1]), signs64)
     ref_l = osteps.betavaegan_step(eg64, d64, oeg64, od64, x.double(), no.double(), e2.double(), e3.double(), beta=25.0,
                                    grad_hook=lambda ph, net: ref_g.__setitem__(
                                        ph, {k: p.grad.detach().clone() for k, p in net.named_parameters()}))
+    taps += _tap_unit_signs((tr.netEG.x_to_mu[1], tr.netEG.x_to_logvar[1], tr.netEG.preprocess[1], tr.netD.lth_features[1]),
+                            signs_hip)
     out = tr.step(x.cuda(), no.cuda(), e2.cuda(), e3.cuda(),
                   grad_hook=lambda ph, net: got_g.__setitem__(
                       ph, {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}))
+    for h in taps:
+        h.remove()
+    assert 0 < len(signs_hip) <= len(signs64), (len(signs64), len(signs_hip))     # (the oracle may run a layer more often)
+    flips = _count_flips(signs_hip, signs64)
     assert 1e-5 < ref_l["D_x"] < 1 - 1e-5, ref_l["D_x"]        # the fp32 sigmoid has not saturated to exactly 0 / 1
     # losses: 1e-4, or 3 x what the reference's own fp32 arithmetic loses against fp64 at these weights (D(x) close to 1
     # makes log(1 - p) sensitive to the fp32 rounding of p)
@@ -538,8 +571,10 @@ def test_gradients_at_trained_weights_vs_oracle(T):
                 continue
             e = float((got_g[ph][k].double() - r).norm() / float(r.norm()))
             e32 = float((ref32_g[ph][k] - r).norm() / float(r.norm()))
-            worst[ph] = max(worst.get(ph, (0.0, "", 0.0)), (e / max(3e-3, 3 * e32), k, e))
-    assert all(w[0] <= 1.0 for w in worst.values()), worst
+            # the stated 3e-3 (it covers one flipped unit at batch 128), the reference's own fp32 error, or -- when the
+            # build and the fp64 oracle disagree on the sign of more than one counted unit -- 1.7e-3 per such unit
+            worst[ph] = max(worst.get(ph, (0.0, "", 0.0)), (e / max(3e-3, 3 * e32, 1e-3 + 1.7e-3 * flips), k, e))
+    assert all(w[0] <= 1.0 for w in worst.values()), (worst, flips)
 
 
 def _smooth_batches(n_it, batch, seed=7):
