@@ -233,6 +233,14 @@ def main():
             dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
+        if os.environ.get("VG_DP_ALONE", "0") == "1":
+            # one GPU, the data-parallel code path: a process group of ONE rank over RCCL, the gradient exchange forced on
+            # (every all-reduce runs, over one rank) -- what a one-GPU box can show of the N > 1 iteration: that it is
+            # captured and replayed like the single-GPU one (`data_parallel.launch_mode`) and what it costs next to it
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     dev = torch.device("cuda", torch.cuda.current_device())
 
     from disentangle_mlp_amd import ops
@@ -240,7 +248,11 @@ def main():
 
     B = args.batch
     arith = ops.CONV_ARITH               # the product default unless VG_CONV_ARITH was exported
-    tr = BetaVAEGANTrainer(device=dev, seed=999, beta=args.beta)
+    alone = world == 1 and dist.is_initialized()
+    if alone:
+        from disentangle_mlp_amd.trainer import FlatGrads
+        FlatGrads.exchange_when_alone = True
+    tr = BetaVAEGANTrainer(device=dev, seed=999, beta=args.beta, data_parallel=True if alone else None)
     ck0 = tr.checkpoint(0)               # the initial state (the reference's seed recipe), cloned: reloaded before the warm-up
     ck0 = {k: ({n: t.clone() for n, t in v.items()} if k.endswith("_model") else __import__("copy").deepcopy(v))
            for k, v in ck0.items()}
@@ -306,14 +318,20 @@ def main():
     dom_ms = ops.stop_timing().get(dominant, []) if not graphed else []
     out = {k: v.clone() for k, v in out.items()}
     comm = None
-    if world > 1:
+    if world > 1 or alone:
         ranks = torch.ones(1, device=dev)
         dist.all_reduce(ranks)                  # how many ranks the transport really connects
         comm = {"ranks_counted_by_all_reduce": int(ranks.item()),
                 "bytes_all_reduced_per_step": sum(f.bytes_reduced for f in flats) // args.steps,
                 "collectives_per_step": sum(f.collectives for f in flats) / args.steps,
-                "exposed_comm_ms_per_step": round(sum(f.exposed_ms() for f in flats) / args.steps, 3),
-                "backend": dist.get_backend()}
+                # measured around the waits of FlatGrads.finish() in eager iterations; inside a replayed graph the join
+                # is a graph edge and cannot be bracketed by events
+                "exposed_comm_ms_per_step": None if graphed else round(sum(f.exposed_ms() for f in flats) / args.steps, 3),
+                "backend": dist.get_backend(),
+                "transport": "own RCCL communicator (rccl.py), all-reduces on a forked side stream"
+                             if all(f.capturable for f in flats) else "torch.distributed async all-reduce",
+                "launch_mode": "HIP graph replay (the all-reduces are nodes of the captured iteration)" if graphed
+                               else "eager (collectives launched from autograd hooks)"}
     for f in flats:
         f.time_finish = False
     # what regime the last timed step ran in: mean D(x), and how much of the gradient that D sends back into the decoder
@@ -436,8 +454,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(B, args.beta)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or alone:
         dist.barrier()
+        from disentangle_mlp_amd import rccl
+        rccl.shutdown()
         dist.destroy_process_group()
 
 

@@ -61,6 +61,7 @@ class FlatGrads:
     all the rings / trees RCCL builds busy."""
 
     exchange_when_alone = False      # tests: run the collectives even in a process group of one
+    own_rccl = __import__("os").environ.get("VG_OWN_RCCL", "1") != "0"     # 0: c10d's collectives on the GPU too (not capturable)
 
     def __init__(self, params, bucket_bytes=8 << 20, direct_bytes=1 << 20, overlap=True, silent=()):
         """``silent``: parameters that never receive a gradient from autograd (the biases whose gradient is defined as
@@ -93,6 +94,19 @@ class FlatGrads:
         self._pending, self._launched, self._direct_done, self._handles = [], [], set(), []
         self._armed = False
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
+        # Transport.  On the GPU with the "nccl" (= RCCL) backend: our own RCCL communicator (rccl.py), all-reduces
+        # enqueued on a side stream forked from / joined to the compute stream by events -- plain kernel launches, so an
+        # iteration containing them can be captured in a HIP graph (c10d's collectives cannot: rccl.py).  Otherwise
+        # (gloo: CPU tests, two ranks sharing one GPU) torch.distributed's async all-reduce.  Creating the communicator
+        # is collective: every rank constructs its trainers in the same order.
+        self._comm = self._side = None
+        if (self.own_rccl and dev.type == "cuda" and dist.is_available() and dist.is_initialized()
+                and dist.get_backend() == "nccl"):
+            from . import rccl
+            self._comm = rccl.communicator()
+            self._side = torch.cuda.Stream(device=dev)
+        self._forked = False
+        self._capturing = False
         # bookkeeping for bench.py: bytes handed to all-reduce since the last reset, and -- when `time_finish` is set --
         # HIP-event pairs around the waits of finish() (how long the compute stream stood still for the exchange)
         self.bytes_reduced, self.collectives = 0, 0
@@ -121,15 +135,32 @@ class FlatGrads:
         self._direct_done.add(i)
         self.bytes_reduced += g.numel() * 4
         self.collectives += 1
-        self._handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+        self._all_reduce(g)
 
     def _launch(self, b):
         bk = self.buckets[b]
         self._launched[b] = True
         self.bytes_reduced += (bk["end"] - bk["start"]) * 4
         self.collectives += 1
-        self._handles.append(dist.all_reduce(self.flat[bk["start"]:bk["end"]], op=dist.ReduceOp.SUM,
-                                             async_op=True))
+        self._all_reduce(self.flat[bk["start"]:bk["end"]])
+
+    @property
+    def capturable(self):
+        """Whether an iteration that exchanges through this object may be captured in a HIP graph."""
+        return self._comm is not None
+
+    def _all_reduce(self, t):
+        if self._comm is None:
+            self._handles.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+            return
+        # own RCCL: fork the side stream from the stream this gradient is final on (the hook runs on the autograd
+        # thread, whose current stream the engine has set to the producing node's), enqueue, join in finish()
+        cur = torch.cuda.current_stream()
+        if torch.cuda.is_current_stream_capturing() != self._capturing:
+            raise RuntimeError("FlatGrads: a gradient hook ran on a stream outside the capture that armed the exchange")
+        self._side.wait_stream(cur)
+        self._comm.all_reduce_sum_(t, self._side)
+        self._forked = True
 
     def zero_and_attach(self):
         """Start of a phase: small gradients -> zeroed views of the flat buffer (autograd
@@ -141,6 +172,8 @@ class FlatGrads:
         self._launched = [False] * len(self.buckets)
         self._direct_done = set()
         self._handles = []
+        self._forked = False
+        self._capturing = self.flat.is_cuda and torch.cuda.is_current_stream_capturing()
         # a 1-rank group still exchanges (sum over one rank): lets a single GPU exercise the RCCL path end to end
         self._armed = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FlatGrads.exchange_when_alone)
 
@@ -155,12 +188,15 @@ class FlatGrads:
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)
-        timed = self.time_finish and self.flat.is_cuda
+        timed = self.time_finish and self.flat.is_cuda and not self._capturing     # (events inside a capture cannot be timed)
         if timed:
             a = torch.cuda.Event(enable_timing=True)
             a.record()
         for h in self._handles:
             h.wait()
+        if self._forked:                         # own RCCL: the compute stream joins the side stream
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._forked = False
         if timed:
             b = torch.cuda.Event(enable_timing=True)
             b.record()
@@ -296,6 +332,9 @@ class _CapturedIteration:
         for k, v in inputs.items():
             self.inputs[k].copy_(v)
         before_nbt = [m._nbt_pending for m in bn_modules]
+        # a data-parallel iteration: the exchange's counters (bench.py's data_parallel block) advance per replay as well
+        self.flats = [f for f in (getattr(trainer, n, None) for n in ("flat_d", "flat_eg", "flat_g", "flat")) if f is not None]
+        before_flat = [(f.bytes_reduced, f.collectives) for f in self.flats]
         host_steps = [{p: float(o.state[p]["step"]) for g in o.param_groups for p in g["params"] if len(o.state[p])}
                       for o in optimizers]
         for o in optimizers:
@@ -315,6 +354,7 @@ class _CapturedIteration:
         # the graph holds raw pointers into the pack cache and the scratch buffers of ops: they live as long as it does
         self._buffers = ops.buffers_in_use()
         self.nbt_delta = [m._nbt_pending - n for m, n in zip(bn_modules, before_nbt)]
+        self.flat_delta = [(f.bytes_reduced - b0, f.collectives - c0) for f, (b0, c0) in zip(self.flats, before_flat)]
         self.fresh = True          # the capture pass already did the host-side bookkeeping of the first replay
 
     def replay(self, inputs, real_label, fake_label):
@@ -333,6 +373,9 @@ class _CapturedIteration:
                 m._nbt_pending += d
             for o in self.optimizers:
                 o.replayed()
+            for f, (db, dc) in zip(self.flats, self.flat_delta):
+                f.bytes_reduced += db
+                f.collectives += dc
         return self.out
 
 
@@ -351,7 +394,11 @@ class _GraphedSteps:
     probe = None      # callable(name, tensor): taps of an (eager) iteration, see BetaVAEGANTrainer._phases
 
     def _graph_init(self, graph, on_gpu, fused_adam, dp):
-        self.graph = (GRAPH_DEFAULT if graph is None else bool(graph)) and on_gpu and fused_adam and not dp
+        """A data-parallel iteration is captured too when its exchange is capturable (FlatGrads on our own RCCL
+        communicator); over torch.distributed's collectives (gloo, VG_OWN_RCCL=0) it stays eager."""
+        dp_ok = (not dp) or (on_gpu and FlatGrads.own_rccl and dist.is_available() and dist.is_initialized()
+                             and dist.get_backend() == "nccl")
+        self.graph = (GRAPH_DEFAULT if graph is None else bool(graph)) and on_gpu and fused_adam and dp_ok
         self._graphs, self._shape_steps = {}, {}
         return self.graph
 
@@ -379,7 +426,9 @@ class _GraphedSteps:
                                                           else [r for v in plans.values() for r in v]))
 
     def _graph_usable(self, optimizers, data, grad_hook):
+        flats = [f for f in (getattr(self, n, None) for n in ("flat_d", "flat_eg", "flat_g", "flat")) if f is not None]
         return (self.graph and grad_hook is None and self.probe is None and ops._timing is None and data.is_cuda
+                and all(f.capturable for f in flats)
                 and all(isinstance(o, HipAdam) and o.device_scalars for o in optimizers)
                 and not torch.cuda.is_current_stream_capturing())
 

@@ -83,7 +83,13 @@ def test_pure_host_entry_points(lib_path):
     assert lib.vg_conv5x5_fwd_bf16split_workspace_bytes(128, 128, 32, 32, 256, 2) == 0          # 256 tiles: no split
     assert lib.vg_conv5x5_fwd_bf16split_workspace_bytes(128, 256, 16, 16, 256, 2) == 4 * 128 * 256 * 8 * 8 * 4
     assert lib.vg_convT5x5_fwd_bf16split_workspace_bytes(128, 256, 16, 16, 128, 2) == 0
-    assert lib.vg_conv5x5_packed_bf16split_bytes(256, 128, 3) == (8 * 25 + 3) * 2 * 3 * 256 * 16
+    # packs: chunks * 25 steps + 6 spare zero steps (the DMA ring's run-ahead), [plane][k-block][cout] x 16 bytes;
+    # fp16 planes (2 | VG_PLANES_F16): + the 16-byte trailer with the inverse of the filter's scale
+    assert lib.vg_conv5x5_packed_bf16split_bytes(256, 128, 3) == (8 * 25 + 6) * 2 * 3 * 256 * 16
+    assert lib.vg_conv5x5_packed_bf16split_bytes(256, 128, 2 | 0x100) == (8 * 25 + 6) * 2 * 2 * 256 * 16 + 16
+    assert lib.vg_conv5x5_packed_bf16split_bytes(256, 128, 3 | 0x100) == 0                     # fp16 planes: two of them
+    assert lib.vg_conv5x5_wgrad_bf16split_workspace_bytes(128, 128, 32, 32, 256, 2, 2 | 0x100) > 0
+    assert lib.vg_absmax(None, 16, None, None) == -1
 
 
 def test_ops_refuse_cpu_tensors():

@@ -132,6 +132,47 @@ def test_rccl_path_in_a_group_of_one():
     assert out.returncode == 0 and "rccl-one-rank ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 
+def test_captured_dp_iteration_equals_eager_dp():
+    """The data-parallel iteration as ONE HIP graph (round 4): gradient exchange on our own RCCL communicator
+    (rccl.py: ncclAllReduce on a side stream forked from / joined to the compute stream -- graph nodes and edges inside
+    the capture; c10d's collectives abort there, profiles/r03_logs/r3_dpgraph.log).  One rank over RCCL on this GPU,
+    exchange forced on: six iterations of a captured data-parallel trainer against an eager data-parallel one -- every
+    loss and every weight bit for bit -- with label flips between replays; the exchange's byte / collective counters
+    advance per replay as in eager iterations."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent("""
+        import os, sys, torch, torch.distributed as dist
+        sys.path.insert(0, os.getcwd())
+        from disentangle_mlp_amd import trainer as T, rccl
+        from oracle import steps as osteps
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        T.FlatGrads.exchange_when_alone = True
+        b = {k: v.cuda() for k, v in osteps.synthetic_batch(8).items()}
+        eager = T.BetaVAEGANTrainer(beta=25.0, data_parallel=True, graph=False)
+        cap = T.BetaVAEGANTrainer(beta=25.0, data_parallel=True, graph=True)
+        assert eager.flat_d.capturable and cap.flat_eg.capturable and cap.graph and not eager.graph
+        labels = [(0.9, 0.1), (0.9, 0.1), (0.9, 0.1), (0.1, 0.1), (0.9, 0.9), (0.9, 0.1)]
+        for it, (rl, fl) in enumerate(labels):
+            want = {k: float(v) for k, v in eager.step(b["data"], b["noise"], b["eps2"], b["eps3"], real_label=rl, fake_label=fl).items()}
+            got = {k: float(v) for k, v in cap.step(b["data"], b["noise"], b["eps2"], b["eps3"], real_label=rl, fake_label=fl).items()}
+            assert got == want, (it, got, want)
+        assert len(cap._graphs) == 1, "the data-parallel iteration was not captured"
+        torch.cuda.synchronize()
+        for n in ("netEG", "netD"):
+            for (k, v), (_, r) in zip(getattr(cap, n).state_dict().items(), getattr(eager, n).state_dict().items()):
+                assert torch.equal(v, r), (n, k)
+        for f, g in ((cap.flat_d, eager.flat_d), (cap.flat_eg, eager.flat_eg)):
+            assert (f.bytes_reduced, f.collectives) == (g.bytes_reduced, g.collectives) and f.collectives > 0
+        rccl.shutdown()
+        dist.destroy_process_group()
+        print("captured-dp ok")
+    """)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "captured-dp ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
 def _gan_worker(rank, port, q):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
