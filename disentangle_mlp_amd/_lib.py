@@ -35,12 +35,12 @@ SIGNATURES = {
     "vg_absmax_affine": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "vg_absmax_multi": (_I, [_P, _I, _P]),
     "vg_conv5x5_pack_bf16split_multi": (_I, [_P, _I, _I, _P]),
-    "vg_convT5x5_fwd_bf16split_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "vg_convT5x5_fwd_bf16split_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
     "vg_convT5x5_fwd_bf16split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P]),
-    "vg_conv5x5_fwd_bf16split_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "vg_conv5x5_fwd_bf16split_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
     "vg_conv5x5_bf16split_fusable": (_I, [_I, _I, _I, _I]),
-    "vg_conv5x5_fwd_bf16split_stats_floats": (_Z, [_I, _I, _I, _I, _I, _I]),
-    "vg_convT5x5_fwd_bf16split_stats_floats": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "vg_conv5x5_fwd_bf16split_stats_floats": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
+    "vg_convT5x5_fwd_bf16split_stats_floats": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
     "vg_convT5x5_s1_thin_bf16split_ok": (_I, [_I, _I, _I, _I]),
     "vg_conv5x5_thin_wgrad_bf16split_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
     "vg_conv5x5_thin_wgrad_bf16split": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _I, _I, _P]),

@@ -161,8 +161,8 @@ __host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 // cross-file internal entry points (not part of the C ABI)
 int vg_internal_wgrad_reduce(const float* slabs, float* dw, int n, int splits, hipStream_t st, int accumulate = 0);
 // conv_ring.hip: stride-2 split-bf16 convolution (mode 0) / transposed convolution (mode 1), 8-wave ring kernel
-size_t vg_internal_ring_workspace_bytes(int mode, int B, int Cin, int H, int W, int Cout);
-size_t vg_internal_ring_stats_floats(int mode, int B, int Cin, int H, int W, int Cout);
+size_t vg_internal_ring_workspace_bytes(int mode, int B, int Cin, int H, int W, int Cout, int planes);
+size_t vg_internal_ring_stats_floats(int mode, int B, int Cin, int H, int W, int Cout, int planes);
 int vg_internal_ring_conv(int mode, const float* x, const void* packed, const float* bias, float* y, int B, int Cin, int H,
                           int W, int Cout, int planes, void* workspace, size_t workspace_bytes, const float* in_scale,
                           const float* in_shift, int in_act, float* stats, size_t stats_floats, const float* in_amax,

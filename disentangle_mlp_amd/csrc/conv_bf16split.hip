@@ -656,9 +656,9 @@ extern "C" int vg_conv5x5_pack_bf16split_multi(const VgPackEntry* entries, int c
 // channels, whose thin tiles (32 cout x 128 / 256 pixels) live here; stride 1 runs here.
 static bool tr_on_ring(int Cout, int stride) { return stride == 2 && Cout > 64; }
 
-extern "C" size_t vg_conv5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride) {
-  if (B <= 0 || Cin <= 0 || Cin % 16 || Cout <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return 0;
-  if (stride == 2) return vg_internal_ring_workspace_bytes(0, B, Cin, H, W, Cout);
+extern "C" size_t vg_conv5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride, int planes) {
+  if (B <= 0 || Cin <= 0 || Cin % 16 || Cout <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2) || !planes_ok(planes)) return 0;
+  if (stride == 2) return vg_internal_ring_workspace_bytes(0, B, Cin, H, W, Cout, planes);
   const int k = fwd_ksplit(B, Cin, H, W, Cout, stride);
   if (k <= 1) return 0;
   return (size_t)k * B * Cout * ((H - 1) / stride + 1) * ((W - 1) / stride + 1) * sizeof(float);
@@ -671,14 +671,14 @@ extern "C" int vg_conv5x5_bf16split_fusable(int transposed, int Cin, int Cout, i
   return transposed ? (tr_on_ring(Cout, stride) ? 1 : 0) : (stride == 2 ? 1 : 0);
 }
 
-extern "C" size_t vg_conv5x5_fwd_bf16split_stats_floats(int B, int Cin, int H, int W, int Cout, int stride) {
-  if (B <= 0 || Cin <= 0 || Cin % 16 || Cout <= 0 || H <= 0 || W <= 0 || stride != 2) return 0;
-  return vg_internal_ring_stats_floats(0, B, Cin, H, W, Cout);
+extern "C" size_t vg_conv5x5_fwd_bf16split_stats_floats(int B, int Cin, int H, int W, int Cout, int stride, int planes) {
+  if (B <= 0 || Cin <= 0 || Cin % 16 || Cout <= 0 || H <= 0 || W <= 0 || stride != 2 || !planes_ok(planes)) return 0;
+  return vg_internal_ring_stats_floats(0, B, Cin, H, W, Cout, planes);
 }
 
-extern "C" size_t vg_convT5x5_fwd_bf16split_stats_floats(int B, int Cin, int H, int W, int Cout, int stride) {
-  if (B <= 0 || Cin <= 0 || Cin % 16 || Cout <= 0 || H <= 0 || W <= 0 || !tr_on_ring(Cout, stride)) return 0;
-  return vg_internal_ring_stats_floats(1, B, Cin, H, W, Cout);
+extern "C" size_t vg_convT5x5_fwd_bf16split_stats_floats(int B, int Cin, int H, int W, int Cout, int stride, int planes) {
+  if (B <= 0 || Cin <= 0 || Cin % 16 || Cout <= 0 || H <= 0 || W <= 0 || !tr_on_ring(Cout, stride) || !planes_ok(planes)) return 0;
+  return vg_internal_ring_stats_floats(1, B, Cin, H, W, Cout, planes);
 }
 
 extern "C" int vg_conv5x5_fwd_bf16split(const float* x, const void* packed, const float* bias, float* y, int B, int Cin,
@@ -693,7 +693,7 @@ extern "C" int vg_conv5x5_fwd_bf16split(const float* x, const void* packed, cons
   if (!fuse_empty(fuse)) return VG_ERR_BAD_ARG;        // vg_conv5x5_bf16split_fusable says which layers take it
   const bf16x8* w = (const bf16x8*)packed;
   const int k = fwd_ksplit(B, Cin, H, W, Cout, stride);
-  if (k > 1 && (!workspace || workspace_bytes < vg_conv5x5_fwd_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride)))
+  if (k > 1 && (!workspace || workspace_bytes < vg_conv5x5_fwd_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride, planes)))
     return VG_ERR_WORKSPACE;
   const XSplit xs = {k, (float*)workspace, fuse ? fuse->in_amax : nullptr};
   if (planes & VG_PLANES_F16_FLAG) {
@@ -704,9 +704,9 @@ extern "C" int vg_conv5x5_fwd_bf16split(const float* x, const void* packed, cons
   return dispatch_x<X_FWD, 1, 3>(x, w, bias, y, B, Cin, H, W, Cout, xs, st);
 }
 
-extern "C" size_t vg_convT5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride) {
-  if (B <= 0 || Cin <= 0 || Cin % 16 || Cout <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return 0;
-  return tr_on_ring(Cout, stride) ? vg_internal_ring_workspace_bytes(1, B, Cin, H, W, Cout) : 0;
+extern "C" size_t vg_convT5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride, int planes) {
+  if (B <= 0 || Cin <= 0 || Cin % 16 || Cout <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2) || !planes_ok(planes)) return 0;
+  return tr_on_ring(Cout, stride) ? vg_internal_ring_workspace_bytes(1, B, Cin, H, W, Cout, planes) : 0;
 }
 
 extern "C" int vg_convT5x5_fwd_bf16split(const float* x, const void* packed, const float* bias, float* y, int B, int Cin,

@@ -746,9 +746,9 @@ int ring_geom(const float* x, const bf16x8* w, const float* bias, float* y, int 
   static_assert(TM == 128 || TM == 256, "pixel tile");
   if constexpr (TM == 128) {
     if (tsw > 8) return launch_ring<RCfg<MODE, 1, 8, 16, WC, FC, FP, NP, F16>>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
-    // transposed, 8-wide images, 256 cout: ring + the two 2 x 10 x 10 patches (24 units per row) exceed the LDS;
-    // the plan sends those layers to the 128-cout tiles
-    if constexpr (MODE == R_TR && WC * FC * 32 == 256) return VG_ERR_BAD_ARG;
+    // transposed, 8-wide images, 256 cout, three planes: ring + the two 2 x 10 x 10 patches (24 units per row) exceed
+    // the LDS; the plan sends those layers to the 128-cout tiles
+    if constexpr (MODE == R_TR && WC * FC * 32 == 256 && NP == 3) return VG_ERR_BAD_ARG;
     else return launch_ring<RCfg<MODE, 2, 8, 8, WC, FC, FP, NP, F16>>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
   } else {   // 256 pixels: whole 16 x 16 tiles only (the plan never picks it for narrower images)
     return launch_ring<RCfg<MODE, 1, 16, 16, WC, FC, FP, NP, F16>>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
@@ -769,8 +769,8 @@ static int ring_dispatch(int variant, const float* x, const bf16x8* w, const flo
     case 0: return ring_geom<MODE, 4, 2, 2, NP, F16>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
     case 1: return ring_geom<MODE, 2, 2, 1, NP, F16>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
     case 2: return ring_geom<MODE, 4, 1, 2, NP, F16>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
-    default:
-      if constexpr (MODE == R_TR) return ring_geom<MODE, 2, 2, 2, NP, F16>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
+    default:      // forward: with fp16 planes only (its patch does not fit beside the ring otherwise)
+      if constexpr (MODE == R_TR || F16) return ring_geom<MODE, 2, 2, 2, NP, F16>(x, w, bias, y, B, Cin, XH, XW, Cout, ksplit, slabs, fu, st);
       return VG_ERR_BAD_ARG;
   }
 }
@@ -788,7 +788,8 @@ struct RingPlan {
   int variant, ksplit;
 };
 
-static RingPlan ring_plan(int mode, int B, int Cin, int XH, int XW, int Cout) {
+static RingPlan ring_plan(int mode, int B, int Cin, int XH, int XW, int Cout, int planes) {
+  const bool f16 = (planes & VG_PLANES_F16_FLAG) != 0;      // two fp16 planes: smaller ring slots and patches, more tiles fit
   const int tsw = (mode == R_FWD) ? (XW - 1) / 2 + 1 : XW, tsh = (mode == R_FWD) ? (XH - 1) / 2 + 1 : XH;
   const int ncls = (mode == R_TR) ? 4 : 1;
   // pixel tiles of 128 (geometry 8 x 16 per image, or 2 images x 8 x 8)
@@ -799,17 +800,23 @@ static RingPlan ring_plan(int mode, int B, int Cin, int XH, int XW, int Cout) {
   // 256-pixel tile when the image has whole 16 x 16 tiles
   if (Cout > 128) p.variant = 0;
   else p.variant = (mode == R_TR && tsw >= 16 && tsh >= 16) ? 3 : 2;
+  // fp16 planes, forward: the 128 cout x 256 px tile fits too (89.6 KB patch + 24 KB ring; with three bf16 planes 170 KB)
+  // -- half the workgroups, half the filter DMA per MFMA -- where whole 16 x 16 tiles still give every CU a workgroup
+  if (f16 && mode == R_FWD && Cout <= 128 && tsw >= 16 && tsh >= 16 && tsw % 16 == 0 && tsh % 16 == 0 &&
+      (long)B * (tsh / 16) * (tsw / 16) * cdiv(Cout, 128) >= 256)
+    p.variant = 3;
   if (g_ring_variant >= 0) p.variant = g_ring_variant;
-  if (p.variant == 3 && (mode == R_FWD || tsw <= 8)) p.variant = 1;
-  if (p.variant == 0 && mode == R_TR && tsw <= 8) p.variant = 2;
+  if (p.variant == 3 && ((mode == R_FWD && !f16) || tsw <= 8 || tsw % 16 || tsh % 16)) p.variant = 1;
+  // transposed, 8-wide images: the 256-cout tile's ring + two 2 x 10 x 10 patches exceed the LDS with three planes
+  if (p.variant == 0 && mode == R_TR && tsw <= 8 && !f16) p.variant = 2;
   const int tn = (p.variant == 0) ? 256 : 128;
   const long wgs = ((p.variant == 3) ? (pt128 + 1) / 2 : pt128) * cdiv(Cout, tn) * ncls;
   p.ksplit = ring_ksplit(wgs, Cin / 16);
   return p;
 }
 
-size_t vg_internal_ring_workspace_bytes(int mode, int B, int Cin, int H, int W, int Cout) {
-  const RingPlan p = ring_plan(mode, B, Cin, H, W, Cout);
+size_t vg_internal_ring_workspace_bytes(int mode, int B, int Cin, int H, int W, int Cout, int planes) {
+  const RingPlan p = ring_plan(mode, B, Cin, H, W, Cout, planes);
   if (p.ksplit <= 1) return 0;
   const size_t yh = (mode == R_FWD) ? (H - 1) / 2 + 1 : 2 * H, yw = (mode == R_FWD) ? (W - 1) / 2 + 1 : 2 * W;
   return (size_t)p.ksplit * B * Cout * yh * yw * sizeof(float);
@@ -817,8 +824,8 @@ size_t vg_internal_ring_workspace_bytes(int mode, int B, int Cin, int H, int W, 
 
 // Floats of the output-statistics buffer ([slot][Cout][2]; one slot per (class, pixel tile, wavefront row)); 0 when
 // the layer runs K-split (its partial outputs never meet in one workgroup: statistics come from a pass over y).
-size_t vg_internal_ring_stats_floats(int mode, int B, int Cin, int H, int W, int Cout) {
-  const RingPlan p = ring_plan(mode, B, Cin, H, W, Cout);
+size_t vg_internal_ring_stats_floats(int mode, int B, int Cin, int H, int W, int Cout, int planes) {
+  const RingPlan p = ring_plan(mode, B, Cin, H, W, Cout, planes);
   if (p.ksplit > 1) return 0;
   const int tsw = (mode == R_FWD) ? (W - 1) / 2 + 1 : W, tsh = (mode == R_FWD) ? (H - 1) / 2 + 1 : H;
   long tiles;
@@ -832,11 +839,11 @@ int vg_internal_ring_conv(int mode, const float* x, const void* packed, const fl
                           int W, int Cout, int planes, void* workspace, size_t workspace_bytes, const float* in_scale,
                           const float* in_shift, int in_act, float* stats, size_t stats_floats, const float* in_amax,
                           hipStream_t st) {
-  const RingPlan p = ring_plan(mode, B, Cin, H, W, Cout);
-  if (p.ksplit > 1 && (!workspace || workspace_bytes < vg_internal_ring_workspace_bytes(mode, B, Cin, H, W, Cout)))
+  const RingPlan p = ring_plan(mode, B, Cin, H, W, Cout, planes);
+  if (p.ksplit > 1 && (!workspace || workspace_bytes < vg_internal_ring_workspace_bytes(mode, B, Cin, H, W, Cout, planes)))
     return VG_ERR_WORKSPACE;
   if ((in_scale == nullptr) != (in_shift == nullptr) || in_act < VG_ACT_NONE || in_act > VG_ACT_LRELU) return VG_ERR_BAD_ARG;
-  if (stats && (p.ksplit > 1 || stats_floats < vg_internal_ring_stats_floats(mode, B, Cin, H, W, Cout))) return VG_ERR_BAD_ARG;
+  if (stats && (p.ksplit > 1 || stats_floats < vg_internal_ring_stats_floats(mode, B, Cin, H, W, Cout, planes))) return VG_ERR_BAD_ARG;
   const bool f16 = (planes & VG_PLANES_F16_FLAG) != 0;
   planes &= 0xff;
   if (f16 && (planes != 2 || !in_amax)) return VG_ERR_BAD_ARG;

@@ -409,11 +409,11 @@ def conv5x5_fwd(x, w, bias, stride, in_affine=None, want_stats=False):
         if in_affine is not None and not fus:
             x, in_affine = _materialize(x, in_affine), None
         if want_stats and fus:
-            n = lib.vg_conv5x5_fwd_bf16split_stats_floats(B, Cin, H, W, Cout, stride)
+            n = lib.vg_conv5x5_fwd_bf16split_stats_floats(B, Cin, H, W, Cout, stride, _planes())
             stats = torch.empty(n, dtype=torch.float32, device=x.device) if n else None
         f = _fusion_struct(x, in_affine, stats)
         pk = _packed_filter(lib, w, Cout, Cin, 2, stride)      # the stride-2 kernel has its own step order
-        need = lib.vg_conv5x5_fwd_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride)    # split-K slabs, deep-K layers only
+        need = lib.vg_conv5x5_fwd_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride, _planes())    # split-K slabs, deep-K layers only
         ws = workspace(need, x.device) if need else None
         with _timed(("conv_fwd", B, Cin, H, W, Cout, stride)):
             check(lib.vg_conv5x5_fwd_bf16split(x.data_ptr(), pk.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W,
@@ -473,11 +473,11 @@ def convT5x5_fwd(x, w, bias, stride, in_affine=None, want_stats=False):
         if in_affine is not None and not fus:
             x, in_affine = _materialize(x, in_affine), None
         if want_stats and fus:
-            n = lib.vg_convT5x5_fwd_bf16split_stats_floats(B, Cin, H, W, Cout, stride)
+            n = lib.vg_convT5x5_fwd_bf16split_stats_floats(B, Cin, H, W, Cout, stride, _planes())
             stats = torch.empty(n, dtype=torch.float32, device=x.device) if n else None
         f = _fusion_struct(x, in_affine, stats)
         pk = _packed_filter(lib, w, Cout, Cin, 3, stride)
-        need = lib.vg_convT5x5_fwd_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride)   # split-K slabs, small grids only
+        need = lib.vg_convT5x5_fwd_bf16split_workspace_bytes(B, Cin, H, W, Cout, stride, _planes())   # split-K slabs, small grids only
         ws = workspace(need, x.device) if need else None
         with _timed(("convT_fwd", B, Cin, H, W, Cout, stride)):
             check(lib.vg_convT5x5_fwd_bf16split(x.data_ptr(), pk.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W,

@@ -427,10 +427,27 @@ class _GraphedSteps:
 
     def _graph_usable(self, optimizers, data, grad_hook):
         flats = [f for f in (getattr(self, n, None) for n in ("flat_d", "flat_eg", "flat_g", "flat")) if f is not None]
+        if self.graph and self._any_module_hooks():      # a replay would never fire them (and a capture would run their
+            return False                                 # Python body once): hooked networks step eagerly
         return (self.graph and grad_hook is None and self.probe is None and ops._timing is None and data.is_cuda
                 and all(f.capturable for f in flats)
                 and all(isinstance(o, HipAdam) and o.device_scalars for o in optimizers)
                 and not torch.cuda.is_current_stream_capturing())
+
+    def _nets(self):
+        return [n for n in (getattr(self, a, None) for a in ("netEG", "netD", "netG", "model")) if n is not None]
+
+    def _any_module_hooks(self):
+        from .model import _has_hooks
+        return _has_hooks([m for net in self._nets() for m in net.modules()])
+
+    def _host_state_key(self):
+        """Host-side switches a capture freezes besides the shapes: part of every capture key, so that flipping one
+        captures anew instead of replaying the old launches."""
+        from . import model as M
+        return (M.FUSE_CONV_BN, M.FUSE_HEAD_BCE, F.DEFER_WGRAD, ops.THIN_SPLIT, ops.USE_PACKED_FILTERS,
+                tuple(net.training for net in self._nets()),
+                tuple(p.requires_grad for net in self._nets() for p in net.parameters()))
 
     def _draw_into(self, cap, name, batch):
         """A latent the caller left to the trainer: drawn from this replica's stream straight into the capture's static
@@ -440,9 +457,10 @@ class _GraphedSteps:
 
     def _run_graphed(self, key, make_inputs, labels, run, optimizers, nets, eager):
         """``key``: everything the capture freezes (shapes, divisors, learning rates, arithmetic).  ``make_inputs(cap)``
-        -> dict of device tensors; ``run(inputs, real_dev, fake_dev)`` -> the iteration on static tensors; ``eager()``:
-        the same iteration launched kernel by kernel (the first GRAPH_WARM_STEPS iterations of a shape, and for good
-        after a failed capture)."""
+        -> dict of device tensors; ``run(inputs, real_dev, fake_dev)`` -> the iteration on static tensors;
+        ``eager(inputs=None)``: the same iteration launched kernel by kernel (the first GRAPH_WARM_STEPS iterations of a
+        shape, and for good after a failed capture -- then on the inputs ``make_inputs`` has already produced)."""
+        key = (key, self._host_state_key())
         cap = self._graphs.get(key)
         if cap is None and self._shape_steps.get(key, 0) < GRAPH_WARM_STEPS:
             self._shape_steps[key] = self._shape_steps.get(key, 0) + 1
@@ -460,8 +478,8 @@ class _GraphedSteps:
                 warnings.warn(f"HIP-graph capture of the training iteration failed ({type(e).__name__}: {e}); "
                               "continuing with eager launches")
                 self.iteration = it0
-                self.graph = False
-                return eager()
+                self.graph = False                   # for good: a capture that fails once is not retried
+                return eager(inputs)                 # (with the latents already drawn: the RNG stream stays an eager run's)
             self._graphs[key] = cap
             self.iteration = it0                     # counted below, once per executed iteration
         out = cap.replay(inputs, *labels)
@@ -532,6 +550,9 @@ class BetaVAEGANTrainer(_GraphedSteps):
     # -- one iteration ------------------------------------------------------------
     def step(self, data, noise=None, eps2=None, eps3=None, real_label=0.9, fake_label=0.1,
              global_batch: Optional[int] = None, grad_hook=None) -> Dict[str, torch.Tensor]:
+        """One iteration; returns the nine loss scalars as device tensors (no host sync).  From the third iteration of a
+        batch shape on the iteration is a HIP-graph replay and the returned tensors are the capture's STATIC outputs: the
+        next replay overwrites them -- ``.clone()`` (or ``float()``) what is kept across steps."""
         if self._graph_usable((self.optimizerD, self.optimizerEG), data, grad_hook):
             return self._step_graphed(data, noise, eps2, eps3, float(real_label), float(fake_label), global_batch)
         # weights change only at the three optimizer steps below: packed filters are reused between them
@@ -554,9 +575,10 @@ class BetaVAEGANTrainer(_GraphedSteps):
             with ops.packed_filter_scope():
                 return self._step(inp["data"], inp["noise"], inp["eps2"], inp["eps3"], real_dev, fake_dev, gb, None)
 
-        def eager():
+        def eager(inp=None):
+            lat = (inp["noise"], inp["eps2"], inp["eps3"]) if inp is not None else (noise, eps2, eps3)
             with ops.packed_filter_scope():
-                return self._step(data, noise, eps2, eps3, real_label, fake_label, global_batch, None)
+                return self._step(data, *lat, real_label, fake_label, global_batch, None)
         return self._run_graphed(key, make_inputs, (real_label, fake_label), run, [self.optimizerD, self.optimizerEG],
                                  (self.netEG, self.netD), eager)
 
@@ -824,9 +846,9 @@ class VAETrainer(_GraphedSteps):
         self.model.train()
 
     def step(self, data, eps=None):
-        def eager():
+        def eager(inp=None):
             with ops.packed_filter_scope():       # one optimizer step at the end: packs live for the iteration
-                return self._step(data, eps)
+                return self._step(data, inp["eps"] if inp is not None else eps)
         if not self._graph_usable((self.optimizer,), data, None):
             return eager()
 
@@ -919,9 +941,10 @@ class GANTrainer(_GraphedSteps):
 
     def step(self, data, noise=None, real_label=0.9, fake_label=0.1, global_batch: Optional[int] = None,
              grad_hook=None):
-        def eager():
+        def eager(inp=None):
             with ops.packed_filter_scope():
-                return self._step(data, noise, real_label, fake_label, global_batch, grad_hook)
+                return self._step(data, inp["noise"] if inp is not None else noise, real_label, fake_label, global_batch,
+                                  grad_hook)
         if not self._graph_usable((self.optimizerD, self.optimizerG), data, grad_hook):
             return eager()
         B = data.size(0)

@@ -134,8 +134,10 @@ typedef struct vg_conv_fusion {
   const float* in_amax;
 } vg_conv_fusion;
 int vg_conv5x5_bf16split_fusable(int transposed, int Cin, int Cout, int stride);
-size_t vg_conv5x5_fwd_bf16split_stats_floats(int B, int Cin, int H, int W, int Cout, int stride);
-size_t vg_convT5x5_fwd_bf16split_stats_floats(int B, int Cin, int H, int W, int Cout, int stride);
+/* (the tile a layer runs on, and with it the slot count and the K split, depends on the arithmetic: two fp16 planes leave
+ * room in the LDS for larger tiles) */
+size_t vg_conv5x5_fwd_bf16split_stats_floats(int B, int Cin, int H, int W, int Cout, int stride, int planes);
+size_t vg_convT5x5_fwd_bf16split_stats_floats(int B, int Cin, int H, int W, int Cout, int stride, int planes);
 size_t vg_conv5x5_packed_bf16split_bytes(int Cout, int Cin, int planes);
 /* w_amax (fp16 planes; NULL otherwise): w_amax[0] >= max |w|, DEVICE memory (vg_absmax / vg_absmax_multi); the pack
  * keeps the inverse of the filter's scale in a 16-byte trailer for the convolution's epilogue */
@@ -150,11 +152,11 @@ typedef struct {
   const float* w_amax; /* as vg_conv5x5_pack_bf16split */
 } VgPackEntry;
 int vg_conv5x5_pack_bf16split_multi(const VgPackEntry* entries, int count, int planes, void* stream);
-size_t vg_conv5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride);
+size_t vg_conv5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride, int planes);
 int vg_conv5x5_fwd_bf16split(const float* x, const void* packed, const float* bias, float* y,
                           int B, int Cin, int H, int W, int Cout, int stride, int planes,
                           void* workspace, size_t workspace_bytes, const vg_conv_fusion* fuse, void* stream);
-size_t vg_convT5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride);
+size_t vg_convT5x5_fwd_bf16split_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride, int planes);
 int vg_convT5x5_fwd_bf16split(const float* x, const void* packed, const float* bias, float* y,
                            int B, int Cin, int H, int W, int Cout, int stride, int planes,
                            void* workspace, size_t workspace_bytes, const vg_conv_fusion* fuse, void* stream);

@@ -80,9 +80,10 @@ def test_pure_host_entry_points(lib_path):
     assert lib.vg_convT5x5_fwd(None, None, None, None, 1, 1, 8, 8, 1, 2, None) == -1
     assert lib.vg_bce_loss(None, 0.9, None, None, 4, 4.0, 1.0, None) == -1
     # split-bf16 convolutions: K-split workspaces are sized on the host (conv_ring.hip's plan)
-    assert lib.vg_conv5x5_fwd_bf16split_workspace_bytes(128, 128, 32, 32, 256, 2) == 0          # 256 tiles: no split
-    assert lib.vg_conv5x5_fwd_bf16split_workspace_bytes(128, 256, 16, 16, 256, 2) == 4 * 128 * 256 * 8 * 8 * 4
-    assert lib.vg_convT5x5_fwd_bf16split_workspace_bytes(128, 256, 16, 16, 128, 2) == 0
+    assert lib.vg_conv5x5_fwd_bf16split_workspace_bytes(128, 128, 32, 32, 256, 2, 3) == 0          # 256 tiles: no split
+    assert lib.vg_conv5x5_fwd_bf16split_workspace_bytes(128, 256, 16, 16, 256, 2, 3) == 4 * 128 * 256 * 8 * 8 * 4
+    assert lib.vg_conv5x5_fwd_bf16split_workspace_bytes(128, 256, 16, 16, 256, 2, 2 | 0x100) == 4 * 128 * 256 * 8 * 8 * 4
+    assert lib.vg_convT5x5_fwd_bf16split_workspace_bytes(128, 256, 16, 16, 128, 2, 3) == 0
     # packs: chunks * 25 steps + 6 spare zero steps (the DMA ring's run-ahead), [plane][k-block][cout] x 16 bytes;
     # fp16 planes (2 | VG_PLANES_F16): + the 16-byte trailer with the inverse of the filter's scale
     assert lib.vg_conv5x5_packed_bf16split_bytes(256, 128, 3) == (8 * 25 + 6) * 2 * 3 * 256 * 16

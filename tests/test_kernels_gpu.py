@@ -636,7 +636,7 @@ def test_conv_fwd_bf16x3_split_k(H):
     from disentangle_mlp_amd import _lib
     lib = _lib.load()
     for (B, Cin, Cout, Hs, s) in ((16, 256, 256, 16, 2), (8, 144, 200, 8, 1), (32, 128, 130, 16, 2)):
-        assert lib.vg_conv5x5_fwd_bf16split_workspace_bytes(B, Cin, Hs, Hs, Cout, s) > 0, (B, Cin, Cout)
+        assert lib.vg_conv5x5_fwd_bf16split_workspace_bytes(B, Cin, Hs, Hs, Cout, s, H._planes()) > 0, (B, Cin, Cout)
         g = torch.Generator().manual_seed(13)
         x = torch.randn(B, Cin, Hs, Hs, generator=g)
         w = torch.randn(Cout, Cin, 5, 5, generator=g) * 0.03
@@ -648,7 +648,7 @@ def test_conv_fwd_bf16x3_split_k(H):
         finally:
             H.CONV_ARITH = prev_arith
         assert_close(y, O.conv5x5(x, w, bias, s), 2e-5, f"split-K {B} {Cin} {Cout}")
-    assert lib.vg_conv5x5_fwd_bf16split_workspace_bytes(128, 128, 32, 32, 256, 2) == 0      # large grid: no split
+    assert lib.vg_conv5x5_fwd_bf16split_workspace_bytes(128, 128, 32, 32, 256, 2, H._planes()) == 0      # large grid: no split
 
 
 # ------------------------------------------------------------------ opt-in bf16x6 (fp32-equivalent) mode
