@@ -614,31 +614,35 @@ __global__ __launch_bounds__(NT) void affine_act_kernel(const float* __restrict_
                                                         const float* __restrict__ shift, float* __restrict__ y, int C,
                                                         int HW, size_t n4, int act, int hw4_shift,
                                                         unsigned* __restrict__ y_amax) {
-  // AA_U units of 16 bytes per thread, a workgroup's units contiguous per round (loads of all rounds in flight together)
-  const size_t base = (size_t)blockIdx.x * (NT * AA_U) + threadIdx.x;
-  float4 v[AA_U];
-  float sc[AA_U], sh[AA_U];
-#pragma unroll
-  for (int u = 0; u < AA_U; ++u) {
-    const size_t i0 = base + (size_t)u * NT;
-    const size_t i = i0 < n4 ? i0 : n4 - 1;                 // tail threads redo the last unit (they take part in the maximum)
-    // HW % 4 == 0: the four elements share a channel
-    const int c = hw4_shift >= 0 ? (int)((unsigned)(i >> hw4_shift) % (unsigned)C) : (int)(((4 * i) / HW) % C);
-    sc[u] = scale[c];
-    sh[u] = shift[c];
-    v[u] = *reinterpret_cast<const float4*>(x + 4 * i);
-  }
+  // A workgroup walks chunks of NT * AA_U units of 16 bytes, grid-stride (<= 2048 workgroups: one maximum and one atomic
+  // per workgroup, not per 4 KB); within a chunk a thread's AA_U units are NT apart (contiguous per round, all loads of
+  // a chunk in flight together).
   unsigned am = 0;
+  for (size_t base = (size_t)blockIdx.x * (NT * AA_U) + threadIdx.x; base < n4 + threadIdx.x;
+       base += (size_t)gridDim.x * (NT * AA_U)) {
+    float4 v[AA_U];
+    float sc[AA_U], sh[AA_U];
 #pragma unroll
-  for (int u = 0; u < AA_U; ++u) {
-    const size_t i0 = base + (size_t)u * NT;
-    float4 o;
-    o.x = act_fwd(fmaf(v[u].x, sc[u], sh[u]), act);
-    o.y = act_fwd(fmaf(v[u].y, sc[u], sh[u]), act);
-    o.z = act_fwd(fmaf(v[u].z, sc[u], sh[u]), act);
-    o.w = act_fwd(fmaf(v[u].w, sc[u], sh[u]), act);
-    if (i0 < n4) *reinterpret_cast<float4*>(y + 4 * i0) = o;
-    am = max(max(am, abs_bits(o.x)), max(max(abs_bits(o.y), abs_bits(o.z)), abs_bits(o.w)));
+    for (int u = 0; u < AA_U; ++u) {
+      const size_t i0 = base + (size_t)u * NT;
+      const size_t i = i0 < n4 ? i0 : n4 - 1;               // past the end: the last unit again (not stored)
+      // HW % 4 == 0: the four elements share a channel
+      const int c = hw4_shift >= 0 ? (int)((unsigned)(i >> hw4_shift) % (unsigned)C) : (int)(((4 * i) / HW) % C);
+      sc[u] = scale[c];
+      sh[u] = shift[c];
+      v[u] = *reinterpret_cast<const float4*>(x + 4 * i);
+    }
+#pragma unroll
+    for (int u = 0; u < AA_U; ++u) {
+      const size_t i0 = base + (size_t)u * NT;
+      float4 o;
+      o.x = act_fwd(fmaf(v[u].x, sc[u], sh[u]), act);
+      o.y = act_fwd(fmaf(v[u].y, sc[u], sh[u]), act);
+      o.z = act_fwd(fmaf(v[u].z, sc[u], sh[u]), act);
+      o.w = act_fwd(fmaf(v[u].w, sc[u], sh[u]), act);
+      if (i0 < n4) *reinterpret_cast<float4*>(y + 4 * i0) = o;
+      am = max(max(am, abs_bits(o.x)), max(max(abs_bits(o.y), abs_bits(o.z)), abs_bits(o.w)));
+    }
   }
   if (y_amax) block_amax_atomic<NT>(am, y_amax);      // max |y| for an fp16-plane consumer (common.hpp)
 }
@@ -734,7 +738,8 @@ extern "C" int vg_affine_act(const float* x, const float* scale, const float* sh
     while ((1 << sh) < hw4) ++sh;
     if ((n4 >> sh) > 0xffffffffULL) sh = -1;
   }
-  hipLaunchKernelGGL(affine_act_kernel, dim3((unsigned)((n4 + NT * AA_U - 1) / (NT * AA_U))), dim3(NT), 0, (hipStream_t)stream, x, scale,
+  const size_t chunks = (n4 + NT * AA_U - 1) / (NT * AA_U);
+  hipLaunchKernelGGL(affine_act_kernel, dim3((unsigned)(chunks < 2048 ? chunks : 2048)), dim3(NT), 0, (hipStream_t)stream, x, scale,
                      shift, y, C, HW, n4, act, sh, (unsigned*)y_amax);
   VG_CHECK_LAUNCH();
   return 0;

@@ -111,6 +111,7 @@ struct RArgs {
   // kernel multiplied the filter by (stored behind the pack).  NULL for bf16 planes.
   const float* in_amax;
   const float* w_unscale;
+  int paired;          // transposed: a workgroup runs two parity classes of its tile (see conv5x5_ring_kernel)
 };
 
 // steps (of 16 k) of the transposed classes before (R, SS), per chunk of 16 channels
@@ -674,8 +675,36 @@ __global__ __launch_bounds__(RNT, 2) void conv5x5_ring_kernel(RArgs A) {
     const int split = bid / A.blocks_per_cls;
     ring_body<C, 0, 0, AFF>(A, lds, bid - split * A.blocks_per_cls, split);
   } else {
-    // [class][split][tile]; class 0 (3x3 taps) first: the longest blocks start earliest
     const int per = A.blocks_per_cls;
+    if (A.paired) {
+      // The four parity classes of a tile read the SAME input patch; launched as four workgroups a whole launch apart,
+      // every class fetched it from HBM again (232 MB per launch of the 256 -> 128 @16 -> 32 layer against 104 MB of
+      // operands: profiles/r04_pmc_dominant_convT.json).  Where the grid allows it, one workgroup runs TWO classes of
+      // its tile back to back -- (3x3 taps, then 2x2) or (3x2, then 2x3): 13 / 12 steps per chunk, so the halves are
+      // balanced and 2 x 128 tiles are ONE round of the 256 CUs (the four-class grid was two rounds with the shortest
+      // class last) -- and the two workgroups of a tile are XCD neighbours in launch order (blocks b, b + 8): the patch
+      // comes from HBM once, from that XCD's L2 afterwards.  [pair][split][tile] per XCD-interleaved index.
+      const int nsplit = gridDim.x / (2 * per);
+      const int xcd = bid & 7, j = bid >> 3;
+      const int pair = j & 1;
+      bid = (j >> 1) * 8 + xcd;                 // in [0, per * nsplit): keeps its XCD (per % 8 == 0, the host checks)
+      const int split = bid / per;
+      bid -= split * per;
+      // pair 0: classes (0,0) then (1,1); pair 1: (0,1) then (1,0)
+#pragma unroll 1
+      for (int k = 0; k < 2; ++k) {
+        const int cls = pair == 0 ? 3 * k : 1 + k;
+        if (k) __syncthreads();                 // the second class restages the LDS
+        switch (cls) {
+          case 0: ring_body<C, 0, 0, AFF>(A, lds, bid, split); break;
+          case 1: ring_body<C, 0, 1, AFF>(A, lds, bid, split); break;
+          case 2: ring_body<C, 1, 0, AFF>(A, lds, bid, split); break;
+          default: ring_body<C, 1, 1, AFF>(A, lds, bid, split); break;
+        }
+      }
+      return;
+    }
+    // [class][split][tile]; class 0 (3x3 taps) first: the longest blocks start earliest
     const int nsplit = gridDim.x / (4 * per);
     const int cls = bid / (per * nsplit);
     bid -= cls * per * nsplit;
@@ -721,7 +750,12 @@ int launch_ring(const float* x, const bf16x8* w, const float* bias, float* y, in
   A.tiles_hw = cdiv(tsh, C::TH) * A.tiles_w;
   A.ntiles_n = cdiv(Cout, C::TN);
   const long per_cls = (long)A.ntiles_n * A.tiles_hw * cdiv(B, C::NB);
-  const long grid = per_cls * C::NCLS * ksplit;
+  // transposed: two classes per workgroup when that still gives every CU a workgroup (and the XCD arithmetic holds)
+  A.paired = (C::NCLS == 4 && per_cls * ksplit * 2 >= 256 && per_cls % 8 == 0) ? 1 : 0;
+#ifdef VG_RING_UNPAIRED      // timing experiments
+  A.paired = 0;
+#endif
+  const long grid = per_cls * (A.paired ? 2 : C::NCLS) * ksplit;
   if (grid <= 0 || grid > 0x7fffffffL) return VG_ERR_BAD_ARG;
   A.blocks_per_cls = (int)per_cls;
   A.cps = cdiv(Cin / 16, ksplit);

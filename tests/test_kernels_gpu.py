@@ -845,7 +845,7 @@ def test_stats_epilogue_at_the_benchmarked_sizes(H, B, transposed, Cin, Cout, Hs
     assert H.conv_fusable(transposed, Cin, Cout, 2)
     lib = __import__("disentangle_mlp_amd._lib", fromlist=["load"]).load()
     wsb = (lib.vg_convT5x5_fwd_bf16split_workspace_bytes if transposed else lib.vg_conv5x5_fwd_bf16split_workspace_bytes)(
-        B, Cin, Hs, Hs, Cout, 2)
+        B, Cin, Hs, Hs, Cout, 2, H._planes())
     if wsb == 0:                                   # not K-split: the epilogue must have run
         assert stats is not None and stats.numel() % (2 * Cout) == 0
     if stats is not None:
