@@ -39,3 +39,11 @@ def enable(path=None):
     except Exception:          # an installation without TunableOp: the default algorithms
         _state["active"] = False
     return _state["active"]
+
+
+def disable():
+    """Switch TunableOp off again (it is process-wide: a user whose other GEMMs should not go through the look-up)."""
+    if _state["active"]:
+        import torch.cuda.tunable as tunable
+        tunable.enable(False)
+    _state["done"], _state["active"] = True, False
