@@ -294,10 +294,21 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
   const bf16x8* dma_ptr = wcls;                     // pack address of the next step to fetch (advanced by dma_next)
   auto dma_next = [&](int slot) {
 #pragma unroll
-    for (int j = 0; j < NDMA; ++j)
+    for (int j = 0; j < NDMA; ++j) {
+#if !defined(VG_RING_DMA_VADDR)
+      // scalar-base form: SGPR-pair base + one 32-bit lane offset, M0 = the slot's LDS address.  The builtin gives every
+      // lane a 64-bit address (a v_lshl_add_u64 per instruction and twice the address registers to read): same-box A/B
+      // 151.7-152.1 against 155.9-156.4 us on the dominant layer (profiles/r04_logs/r4_saddr.log).  hipcc does not see
+      // this VMEM instruction; its own waits for the staging loads only become more conservative (completion is in order),
+      // the waits for the DMA are the counted ones of this file.
+      const unsigned m0v = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(lds + RING0 + slot * SLOTU + dma_dst[j]);
+      asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(dma_src[j]), "s"(dma_ptr), "s"(m0v) : "memory", "m0");
+#else
       __builtin_amdgcn_global_load_lds((const void*)((const char*)dma_ptr + dma_src[j]),
                                        (__attribute__((address_space(3))) void*)(lds + RING0 + slot * SLOTU + dma_dst[j]),
                                        16, 0, 0);
+#endif
+    }
     dma_ptr += wstep;
   };
 
