@@ -32,5 +32,9 @@ with ops.packed_filter_scope():
         w = 0.05 * torch.randn(*((co, ci, 5, 5) if kind == "fwd" else (ci, co, 5, 5)), device="cuda")
         fn = (lambda: ops.conv5x5_fwd(x, w, None, 2)) if kind == "fwd" else (lambda: ops.convT5x5_fwd(x, w, None, 2))
         out.append(f"{kind} {timeit(fn)*1e3:7.1f} us")
+        # the same launch reading its input through a BatchNorm + ReLU (the forward launches of a fused chain)
+        sc, sh = 0.5 + torch.rand(ci, device="cuda"), torch.randn(ci, device="cuda")
+        fa = (lambda: ops.conv5x5_fwd(x, w, None, 2, in_affine=(sc, sh, 1))) if kind == "fwd" else (lambda: ops.convT5x5_fwd(x, w, None, 2, in_affine=(sc, sh, 1)))
+        out.append(f"{kind}+BN {timeit(fa)*1e3:7.1f} us")
 names = {1: "no DMA", 2: "no barrier", 4: "no staging", 8: "no vmcnt wait", 16: "no B reads", 32: "no A reads", 64: "no MFMA"}
 print(f"abl {bits:3d} [{', '.join(v for k, v in names.items() if bits & k) or 'full'}]: " + " | ".join(out), flush=True)
