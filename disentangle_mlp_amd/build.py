@@ -26,7 +26,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", f"-I{INCLUDE}",
          "-Wno-unused-result"]
 # conv_ring.hip unrolls the 25 K steps of a channel chunk (compile-time tap offsets, static fragment registers):
 # past LLVM's default pragma-unroll budget the loop stays rolled and the fragment arrays go to scratch
-FILE_FLAGS = {"conv_ring.hip": ["-mllvm", "-pragma-unroll-threshold=131072"]}
+FILE_FLAGS = {"conv_ring.hip": ["-mllvm", "-pragma-unroll-threshold=131072", "-Wno-inline-asm"]}
 
 
 def _hipcc():

@@ -136,7 +136,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 // loads from the kernel argument itself.  (Round 3 selected between in_scale and a __device__ constant at run time: the
 // compiler could not tell the address space, loaded the 16 coefficients of a unit with flat_load and drained vmcnt(0)
 // -- the whole filter ring -- in front of every unit's arithmetic: ~2000 cycles per staging event.)
-template <class C, int R, int SS, bool AFF>
+// R2 >= 0 (transposed form only): the workgroup computes TWO output-parity classes of its tile, (R, SS) and (R2, SS2),
+// from ONE staged patch: per chunk the K steps of the first class, then those of the second, each into its own
+// accumulators; the filter DMA alternates between the two classes' streams (which stream a step belongs to is a
+// compile-time property of the unrolled body).  Half the staging work and input traffic of two separate passes.
+template <class C, int R, int SS, bool AFF, int R2 = -1, int SS2 = -1>
 __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, int split) {
   constexpr int MODE = C::MODE, S = C::S, NB = C::NB, TH = C::TH, TW = C::TW, PH = C::PH, PW = C::PW;
   constexpr int COLS = C::COLS, ROWU = C::ROWU, IMGU = C::IMGU, NQ = C::NQ, FC = C::FC, FP = C::FP, NP = C::NP;
@@ -145,7 +149,13 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
   constexpr bool F16 = C::F16;
   constexpr int NTH = (MODE == R_FWD) ? 5 : (5 - R + 1) / 2;     // taps along h / w in this class
   constexpr int NTW = (MODE == R_FWD) ? 5 : (5 - SS + 1) / 2;
-  constexpr int NSTEP = NTH * NTW;                                // K steps per 16-channel chunk (FWD: 25)
+  constexpr bool TWO = R2 >= 0;
+  static_assert(!TWO || MODE == R_TR, "two classes: transposed form");
+  constexpr int NTH2 = TWO ? (5 - R2 + 1) / 2 : 0, NTW2 = TWO ? (5 - SS2 + 1) / 2 : 1;
+  constexpr int NA = NTH * NTW, NB2 = NTH2 * NTW2;                // K steps of the first / second class per chunk
+  constexpr int NSTEP = NA + NB2;                                 // K steps per 16-channel chunk (FWD: 25)
+  constexpr int NACC = TWO ? 2 : 1;
+  static_assert(!TWO || NA >= NSLOT, "the prologue's DMAs all belong to the first class");
   constexpr int PSTEP = (MODE == R_FWD) ? S : 1;
   constexpr int RING0 = 0, PATCH0 = C::RINGU, DUMMY = C::RINGU + C::PATCHU;
 
@@ -280,6 +290,7 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
   const size_t wstep = (size_t)2 * NP * CoutP;      // units per step in the pack
   const int nchunks = Cin / 16;
   const bf16x8* wcls = A.w + (size_t)((MODE == R_FWD) ? 0 : tr_taps_before(R, SS)) * nchunks * wstep;
+  const bf16x8* dma_ptr2 = A.w + (size_t)(TWO ? tr_taps_before(R2 < 0 ? 0 : R2, SS2 < 0 ? 0 : SS2) : 0) * nchunks * wstep;
   // DMA instruction i of a step covers units [64 i, 64 i + 64) of the slot image [plane][kb][TN]
   unsigned dma_src[NDMA];     // per-lane BYTE offset within a pack step
   int dma_dst[NDMA];          // wave-uniform unit offset within the slot
@@ -291,8 +302,9 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
     dma_src[j] = 16u * (unsigned)(row * CoutP + n0 + col);
     dma_dst[j] = i * 64;
   }
-  const bf16x8* dma_ptr = wcls;                     // pack address of the next step to fetch (advanced by dma_next)
-  auto dma_next = [&](int slot) {
+  const bf16x8* dma_ptr1 = wcls;                    // pack address of the next step to fetch (advanced by dma_next)
+  auto dma_next = [&](int slot, bool second = false) {
+    const bf16x8*& dma_ptr = second ? dma_ptr2 : dma_ptr1;
 #pragma unroll
     for (int j = 0; j < NDMA; ++j) {
 #if !defined(VG_RING_DMA_VADDR)
@@ -323,17 +335,18 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
     base_b[f] = PATCH0 + (nb * PH + PSTEP * (r / TW)) * ROWU + r % TW + ((MODE == R_TR) ? kb * IMGU : 0);
   }
 
-  f32x16 acc[FC][FP];
+  f32x16 accs[NACC][FC][FP];
 #pragma unroll
-  for (int g = 0; g < FC; ++g)
+  for (int a = 0; a < NACC; ++a)
 #pragma unroll
-    for (int f = 0; f < FP; ++f)
+    for (int g = 0; g < FC; ++g)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[g][f][r] = 0.f;
+      for (int f = 0; f < FP; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accs[a][g][f][r] = 0.f;
 
   const int c_begin = split * A.cps, c_end = min(c_begin + A.cps, nchunks);
   const int nsteps = (c_end - c_begin) * NSTEP;     // this workgroup's K steps
-  const int st0 = c_begin * NSTEP;
 
   // patch offset (units) of K step `s` of a chunk for k-block `k`, relative to base_b: FWD buffer = 8-channel half
   auto fwd_tap_off = [](int t) constexpr { return (t / 5) * ROWU + ((t % 5) & 1) * COLS + ((t % 5) >> 1); };
@@ -343,6 +356,7 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
       const int tap = (s < 12) ? 2 * s + k : (s == 12 ? 24 : 2 * (s - 13) + k);
       return half * BUFU + fwd_tap_off(tap);
     } else {
+      if (TWO && s >= NA) return (NTMAX - 1 - (s - NA) / NTW2) * ROWU + (NTMAX - 1 - (s - NA) % NTW2);
       return (NTMAX - 1 - s / NTW) * ROWU + (NTMAX - 1 - s % NTW);
     }
   };
@@ -366,7 +380,8 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
   };
   // MFMA i of a step (i < NMF): plane products with index sum < NP, smallest terms first, all fragments per product
   constexpr int NPROD = NP * (NP + 1) / 2, NMF = NPROD * FC * FP;
-  auto mfma_one = [&](int buf, int i) {
+  auto mfma_one = [&](int buf, int i, int a = 0) {
+    auto& acc = accs[a];
     const int pr = i / (FC * FP), g = (i / FP) % FC, f = i % FP;
     int pa = 0, pb = 0, n = 0;                       // pr-th pair in the order (sum = NP-1 .. 0; pa = sum .. 0)
 #pragma unroll
@@ -392,7 +407,8 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
   // a step's MFMAs with the next step's fragment reads spread between them (one read per RS MFMAs), pinned
   constexpr int RS = (NMF / NRD) > 0 ? (NMF / NRD) : 1;
   // ---- prologue: first patch buffer, ring slots 0..2, fragments of step 0
-  dma_ptr += (size_t)st0 * wstep;
+  dma_ptr1 += (size_t)c_begin * NA * wstep;
+  dma_ptr2 += (size_t)c_begin * NB2 * wstep;
 #pragma unroll
   for (int i = 0; i < NSLOT; ++i) dma_next(i);
   stage_load(c_begin * 16);
@@ -451,16 +467,16 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
         constexpr int RPM = (NRD + H2N - 1) / H2N;           // fragment reads per MFMA of H2
 #pragma unroll
         for (int i = 0; i < H1N; ++i)
-          if (!(abl & 64)) mfma_one(cur, i);
+          if (!(abl & 64)) mfma_one(cur, i, (TWO && s >= NA) ? 1 : 0);
         __builtin_amdgcn_sched_barrier(0);
         if (!(abl & 2) && early) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = H1N; i < NMF; ++i) {
           const int j = i - H1N;
-          if (!(abl & 64)) mfma_one(cur, i);
+          if (!(abl & 64)) mfma_one(cur, i, (TWO && s >= NA) ? 1 : 0);
           if (j == 0) {
-            if (!(abl & 1)) dma_next(slot);                // step k+3 into the slot read during body k-1
+            if (!(abl & 1)) dma_next(slot, TWO && (s + NSLOT) % NSTEP >= NA);      // step k+3 into the slot read during body k-1
             if (ld && !(abl & 4)) {
               if constexpr (MODE == R_FWD) stage_load(ch * 16 + (s == 0 ? 8 : 16));
               else stage_load((ch + 1) * 16);
@@ -493,7 +509,7 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
 #define VG_RING_PLACE 0
 #endif
       auto mem_block = [&]() {
-        if (!(abl & 1)) dma_next(slot);                    // step k+NSLOT into the slot read during body k-1
+        if (!(abl & 1)) dma_next(slot, TWO && (s + NSLOT) % NSTEP >= NA);          // step k+NSLOT into the slot read during body k-1
         if (ld && !(abl & 4)) {
           if constexpr (MODE == R_FWD) stage_load(ch * 16 + (s == 0 ? 8 : 16));
           else stage_load((ch + 1) * 16);
@@ -509,7 +525,7 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
       }
 #pragma unroll
       for (int i = 0; i < NMF; ++i) {
-        if (!(abl & 64)) mfma_one(cur, i);
+        if (!(abl & 64)) mfma_one(cur, i, (TWO && s >= NA) ? 1 : 0);
 #ifdef VG_RING_STAMP
         if (i < 12) asm volatile("s_memtime %0" : "=s"(tm[i]));
 #endif
@@ -593,11 +609,13 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
   if constexpr (F16) {   // undo the two operands' power-of-two scales (two exact multiplications: no intermediate overflow)
     const float w_unscale = *A.w_unscale;
 #pragma unroll
-    for (int g = 0; g < FC; ++g)
+    for (int a = 0; a < NACC; ++a)
 #pragma unroll
-      for (int f = 0; f < FP; ++f)
+      for (int g = 0; g < FC; ++g)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][f][r] = acc[g][f][r] * x_unscale * w_unscale;
+        for (int f = 0; f < FP; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) accs[a][g][f][r] = accs[a][g][f][r] * x_unscale * w_unscale;
   }
 
   const int YH = A.YH, YW = A.YW;
@@ -610,21 +628,24 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
 #pragma unroll
     for (int i = 0; i < NMF && i < 12; ++i) o2[4 + i] = tm[i];
   }
-  if (false) {
+  const bool emit_stats = false;
 #else
-  // ---- optional: per-channel sums of the output for the next BatchNorm (ksplit == 1 only: the host says so)
-  if (A.stats) {
+  const bool emit_stats = A.stats != nullptr;
 #endif
+  // one class's statistics + output (two classes: called twice)
+  auto emit = [&](auto& acc, int Rc, int SSc) {
+  // ---- optional: per-channel sums of the output for the next BatchNorm (ksplit == 1 only: the host says so)
+  if (emit_stats) {
     bool pokf[FP];
 #pragma unroll
     for (int f = 0; f < FP; ++f) {
       const int m = (wp * FP + f) * 32 + l32;
       const int nb = m / (TH * TW), r = m % (TH * TW);
       const int th = th0 + r / TW, tw = tw0 + r % TW;
-      const int oh = (MODE == R_FWD) ? th : S * th + R, ow = (MODE == R_FWD) ? tw : S * tw + SS;
+      const int oh = (MODE == R_FWD) ? th : S * th + Rc, ow = (MODE == R_FWD) ? tw : S * tw + SSc;
       pokf[f] = (b0 + nb) < A.B && oh < YH && ow < YW;
     }
-    const int cls = (MODE == R_FWD) ? 0 : 2 * R + SS;
+    const int cls = (MODE == R_FWD) ? 0 : 2 * Rc + SSc;
     const int slot = (cls * (A.blocks_per_cls / A.ntiles_n) + pt) * C::WP + wp;
     float* sb = A.stats + (size_t)slot * Cout * 2;
 #pragma unroll
@@ -657,8 +678,8 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
     const int m = (wp * FP + f) * 32 + l32;
     const int nb = m / (TH * TW), r = m % (TH * TW);
     const int th = th0 + r / TW, tw = tw0 + r % TW, b = b0 + nb;
-    const int oh = (MODE == R_FWD) ? th : S * th + R;
-    const int ow = (MODE == R_FWD) ? tw : S * tw + SS;
+    const int oh = (MODE == R_FWD) ? th : S * th + Rc;
+    const int ow = (MODE == R_FWD) ? tw : S * tw + SSc;
     const bool pok = b < A.B && oh < YH && ow < YW;
     float* yb = A.y + (size_t)split * A.ysplit + ((size_t)b * Cout * YH + oh) * YW + ow;
 #pragma unroll
@@ -676,6 +697,9 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
       }
     }
   }
+  };
+  emit(accs[0], R, SS);
+  if constexpr (TWO) emit(accs[1], R2, SS2);
 }
 
 template <class C, bool AFF>
@@ -701,18 +725,9 @@ __global__ __launch_bounds__(RNT, 2) void conv5x5_ring_kernel(RArgs A) {
       bid = (j >> 1) * 8 + xcd;                 // in [0, per * nsplit): keeps its XCD (per % 8 == 0, the host checks)
       const int split = bid / per;
       bid -= split * per;
-      // pair 0: classes (0,0) then (1,1); pair 1: (0,1) then (1,0)
-#pragma unroll 1
-      for (int k = 0; k < 2; ++k) {
-        const int cls = pair == 0 ? 3 * k : 1 + k;
-        if (k) __syncthreads();                 // the second class restages the LDS
-        switch (cls) {
-          case 0: ring_body<C, 0, 0, AFF>(A, lds, bid, split); break;
-          case 1: ring_body<C, 0, 1, AFF>(A, lds, bid, split); break;
-          case 2: ring_body<C, 1, 0, AFF>(A, lds, bid, split); break;
-          default: ring_body<C, 1, 1, AFF>(A, lds, bid, split); break;
-        }
-      }
+      // pair 0: classes (0,0) [3x3 taps] + (1,1) [2x2]; pair 1: (0,1) [3x2] + (1,0) [2x3] -- from ONE staged patch
+      if (pair == 0) ring_body<C, 0, 0, AFF, 1, 1>(A, lds, bid, split);
+      else ring_body<C, 0, 1, AFF, 1, 0>(A, lds, bid, split);
       return;
     }
     // [class][split][tile]; class 0 (3x3 taps) first: the longest blocks start earliest
