@@ -60,7 +60,7 @@ def _build_one(out, bdir_name, extra, force, verbose):
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
-    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
         list(ex.map(cc, jobs))
     objs = [os.path.join(bdir, s[:-4] + ".o") for s in srcs]
     if jobs or any(_newer(o, out) for o in objs):        # also after an object was compiled by hand
@@ -72,11 +72,15 @@ def _build_one(out, bdir_name, extra, force, verbose):
 
 
 def build(force=False, verbose=True, tuning=True):
-    """Compiles every HIP source; returns the product library's path."""
-    out = _build_one(OUT, "", [], force, verbose)
-    if tuning:
-        _build_one(OUT_TUNING, "tuning", ["-DVG_TUNING"], force, verbose)
-    return out
+    """Compiles every HIP source; returns the product library's path.  The two libraries are built side by side:
+    conv_ring.hip (its unrolled K loop, 100+ kernel instantiations) is minutes of one compiler thread in each."""
+    if not tuning:
+        return _build_one(OUT, "", [], force, verbose)
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        a = ex.submit(_build_one, OUT, "", [], force, verbose)
+        b = ex.submit(_build_one, OUT_TUNING, "tuning", ["-DVG_TUNING"], force, verbose)
+        b.result()
+        return a.result()
 
 
 if __name__ == "__main__":

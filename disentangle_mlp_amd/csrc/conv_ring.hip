@@ -726,8 +726,10 @@ __global__ __launch_bounds__(RNT, 2) void conv5x5_ring_kernel(RArgs A) {
       const int split = bid / per;
       bid -= split * per;
       // pair 0: classes (0,0) [3x3 taps] + (1,1) [2x2]; pair 1: (0,1) [3x2] + (1,0) [2x3] -- from ONE staged patch
-      if (pair == 0) ring_body<C, 0, 0, AFF, 1, 1>(A, lds, bid, split);
-      else ring_body<C, 0, 1, AFF, 1, 0>(A, lds, bid, split);
+      if constexpr (C::F16) {     // (the host pairs fp16-plane launches only: with three planes two accumulator sets spill)
+        if (pair == 0) ring_body<C, 0, 0, AFF, 1, 1>(A, lds, bid, split);
+        else ring_body<C, 0, 1, AFF, 1, 0>(A, lds, bid, split);
+      }
       return;
     }
     // [class][split][tile]; class 0 (3x3 taps) first: the longest blocks start earliest
@@ -777,7 +779,7 @@ int launch_ring(const float* x, const bf16x8* w, const float* bias, float* y, in
   A.ntiles_n = cdiv(Cout, C::TN);
   const long per_cls = (long)A.ntiles_n * A.tiles_hw * cdiv(B, C::NB);
   // transposed: two classes per workgroup when that still gives every CU a workgroup (and the XCD arithmetic holds)
-  A.paired = (C::NCLS == 4 && per_cls * ksplit * 2 >= 256 && per_cls % 8 == 0) ? 1 : 0;
+  A.paired = (C::NCLS == 4 && C::F16 && per_cls * ksplit * 2 >= 256 && per_cls % 8 == 0) ? 1 : 0;
 #ifdef VG_RING_UNPAIRED      // timing experiments
   A.paired = 0;
 #endif

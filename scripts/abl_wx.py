@@ -15,7 +15,7 @@ from disentangle_mlp_amd import _lib
 if bits:
     _lib.LIB_PATH = os.path.join(ROOT, "experiments", "abl", f"libabl_wx_{bits}.so")
 from disentangle_mlp_amd import ops
-ops.CONV_ARITH = "bf16x6"
+ops.CONV_ARITH = os.environ.get("VG_CONV_ARITH", "fp16x3")
 B = 128
 def timeit(fn, n=15):
     for _ in range(60): fn()          # the clock takes tens of launches to settle after idle
