@@ -278,3 +278,66 @@ def test_accumulate_param_grads_adds_inside_the_second_pass(monkeypatch):
     loss().backward()                                           # no context: autograd's own accumulation
     assert torch.allclose(w.grad, gw, rtol=1e-6, atol=1e-6) and len(calls) == 2
 
+
+
+def test_captured_graph_keeps_the_buffers_it_points_at_alive():
+    """ADVICE (round 3, medium): a captured HIP graph holds raw device pointers into the pack cache and the scratch
+    buffers of `ops`; `packed_filter_scope.__enter__` rebuilds the cache once it exceeds `_PACK_CACHE_MAX` entries, and a
+    workspace is replaced when it grows.  `_CapturedIteration` therefore keeps `ops.buffers_in_use()`: the tensors outlive
+    the cache entries that pointed at them.  Host logic only (CPU tensors stand in for the device buffers)."""
+    import gc
+    import weakref
+    from disentangle_mlp_amd import ops
+    saved = dict(ops._pack_cache), dict(ops._workspaces), dict(ops._pack_scratch)
+    try:
+        ops._pack_cache.clear(), ops._workspaces.clear(), ops._pack_scratch.clear()
+        for i in range(ops._PACK_CACHE_MAX + 2):                       # more entries than the cache tolerates
+            ops._pack_cache[(i, 2, 2, (1,), 3)] = [True, 0, torch.zeros(8)]
+        ops._workspaces[("cpu", None, 0)] = torch.zeros(16, dtype=torch.uint8)
+        held = ops.buffers_in_use()                                      # what a capture keeps
+        refs = [weakref.ref(t) for t in held]
+        assert len(held) == ops._PACK_CACHE_MAX + 3
+        with ops.packed_filter_scope():                                  # the next trainer's scope: the cache is rebuilt
+            assert len(ops._pack_cache) == 0
+        ops._workspaces[("cpu", None, 0)] = torch.zeros(32, dtype=torch.uint8)      # ... and the workspace regrown
+        gc.collect()
+        assert all(r() is not None for r in refs)                        # alive: the "graph" still owns them
+        del held
+        gc.collect()
+        assert all(r() is None for r in refs)                            # and gone with it
+    finally:
+        ops._pack_cache.clear(), ops._workspaces.clear(), ops._pack_scratch.clear()
+        ops._pack_cache.update(saved[0]), ops._workspaces.update(saved[1]), ops._pack_scratch.update(saved[2])
+
+
+def test_rccl_unique_id_survives_the_broadcast_box():
+    """rccl.Communicator hands the 128 bytes of ncclGetUniqueId to the other ranks through a Python `bytes`; a c_char
+    array field reads back truncated at its first NUL (the first version of the binding: ncclCommInitRank then timed
+    out on a mangled id), so the struct is c_ubyte and is copied with string_at / memmove."""
+    import ctypes
+    from disentangle_mlp_amd import rccl
+    uid = rccl._UniqueId()
+    assert ctypes.sizeof(uid) == 128
+    pattern = bytes([0, 7, 0, 0, 255, 1] + [i % 251 for i in range(122)])          # NULs early on
+    ctypes.memmove(ctypes.byref(uid), pattern, 128)
+    box = ctypes.string_at(ctypes.byref(uid), 128)
+    assert box == pattern
+    back = rccl._UniqueId()
+    ctypes.memmove(ctypes.byref(back), box, 128)
+    assert bytes(back.internal) == pattern
+
+
+def test_fp16x3_is_the_default_arithmetic_and_planes_codes_match_the_header():
+    import re
+    from disentangle_mlp_amd import ops
+    assert ops.CONV_ARITH == __import__("os").environ.get("VG_CONV_ARITH", "fp16x3")
+    hdr = open(__import__("os").path.join(__import__("os").path.dirname(ops.__file__), "..", "include", "vaegan_hip.h")).read()
+    flag = int(re.search(r"#define VG_PLANES_F16 (0x[0-9a-fA-F]+)", hdr).group(1), 16)
+    assert flag == ops.PLANES_F16
+    prev = ops.CONV_ARITH
+    try:
+        for mode, planes in (("fp32", 0), ("bf16x3", 2), ("bf16x6", 3), ("fp16x3", 2 | flag)):
+            ops.CONV_ARITH = mode
+            assert ops._planes() == planes and ops._thin_planes() == (3 if mode == "fp16x3" else planes)
+    finally:
+        ops.CONV_ARITH = prev
