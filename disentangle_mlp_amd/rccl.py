@@ -63,18 +63,35 @@ class Communicator:
 
     def __init__(self):
         import torch.distributed as dist
-        lib = _load()
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        uid = _UniqueId()
-        if self.rank == 0:
-            _check(lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
-        box = [ctypes.string_at(ctypes.byref(uid), 128) if self.rank == 0 else None]
+        self._comm = ctypes.c_void_p()
+        uid, box = _UniqueId(), [None]
+        try:
+            lib = _load()
+            if self.rank == 0:
+                _check(lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+                box = [ctypes.string_at(ctypes.byref(uid), 128)]
+        except Exception as e:                               # rank 0 tells the others (None) instead of leaving them waiting
+            self._error = e
         if self.world > 1:
             dist.broadcast_object_list(box, src=0)          # rendezvous over the group that already exists
-        assert len(box[0]) == 128
-        ctypes.memmove(ctypes.byref(uid), box[0], 128)
-        self._comm = ctypes.c_void_p()
-        _check(lib.ncclCommInitRank(ctypes.byref(self._comm), self.world, uid, self.rank), "ncclCommInitRank")
+        err = getattr(self, "_error", None)
+        if box[0] is None:
+            err = err or RuntimeError("rank 0 could not create an RCCL unique id")
+        else:
+            try:
+                ctypes.memmove(ctypes.byref(uid), box[0], 128)
+                _check(_load().ncclCommInitRank(ctypes.byref(self._comm), self.world, uid, self.rank), "ncclCommInitRank")
+            except Exception as e:
+                err = e
+        # every rank learns whether EVERY rank has a communicator: one that failed alone must not leave the others on a
+        # transport it does not have
+        ok = torch.tensor([0 if err is not None else 1], device="cuda")
+        if self.world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            self.close()
+            raise RuntimeError(f"RCCL communicator not available on every rank ({err or 'another rank failed'})")
         self.device = torch.cuda.current_device()
 
     def all_reduce_sum_(self, t, stream):
@@ -95,15 +112,22 @@ _comms = {}
 
 def communicator():
     """The process's communicator for the current device (created on first use: a collective call -- every rank must
-    reach it)."""
+    reach it), or None when it could not be created on every rank (decided once, by all ranks together: the callers
+    then stay on torch.distributed's collectives)."""
     dev = torch.cuda.current_device()
-    c = _comms.get(dev)
-    if c is None:
-        c = _comms[dev] = Communicator()
-    return c
+    if dev not in _comms:
+        try:
+            _comms[dev] = Communicator()
+        except Exception as e:
+            import warnings
+            warnings.warn(f"own RCCL communicator unavailable ({e}); the gradient exchange uses torch.distributed's "
+                          "collectives and data-parallel iterations stay eager")
+            _comms[dev] = None
+    return _comms[dev]
 
 
 def shutdown():
     for c in _comms.values():
-        c.close()
+        if c is not None:
+            c.close()
     _comms.clear()

@@ -103,8 +103,8 @@ class FlatGrads:
         if (self.own_rccl and dev.type == "cuda" and dist.is_available() and dist.is_initialized()
                 and dist.get_backend() == "nccl"):
             from . import rccl
-            self._comm = rccl.communicator()
-            self._side = torch.cuda.Stream(device=dev)
+            self._comm = rccl.communicator()          # None: not available on every rank (warned once) -> c10d, eager
+            self._side = torch.cuda.Stream(device=dev) if self._comm is not None else None
         self._forked = False
         self._capturing = False
         # bookkeeping for bench.py: bytes handed to all-reduce since the last reset, and -- when `time_finish` is set --
@@ -397,7 +397,7 @@ class _GraphedSteps:
         """A data-parallel iteration is captured too when its exchange is capturable (FlatGrads on our own RCCL
         communicator); over torch.distributed's collectives (gloo, VG_OWN_RCCL=0) it stays eager."""
         dp_ok = (not dp) or (on_gpu and FlatGrads.own_rccl and dist.is_available() and dist.is_initialized()
-                             and dist.get_backend() == "nccl")
+                             and dist.get_backend() == "nccl")      # (+ FlatGrads.capturable, checked per step)
         self.graph = (GRAPH_DEFAULT if graph is None else bool(graph)) and on_gpu and fused_adam and dp_ok
         self._graphs, self._shape_steps = {}, {}
         return self.graph
