@@ -34,6 +34,9 @@ constexpr int RNT = 512;          // 8 wavefronts
 #ifndef VG_RING_SLOTS
 #define VG_RING_SLOTS 3
 #endif
+#ifndef VG_RING_REGF
+#define VG_RING_REGF 0
+#endif
 constexpr int ring_slots(bool f16, int slotu, int patchu) {
   if (!f16) return 3;
   int n = VG_RING_SLOTS;
@@ -173,6 +176,7 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
 #define VG_RING_STAGGER 0
 #endif
   constexpr bool STG = VG_RING_STAGGER != 0;
+  static_assert(!(STG && VG_RING_REGF), "stagger build: DMA path only");
   const bool early = STG && wid >= 4;                             // wave-uniform: meets each barrier half a body late
   const bool late = wid >= 4;      // wave-uniform: the second-dispatched half (timing experiments VG_RING_PLACE = 1, 2)
   const int kb = lane >> 5, l32 = lane & 31;
@@ -323,6 +327,23 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
     }
     dma_ptr += wstep;
   };
+  // Filter through registers instead (fp16 planes, -DVG_RING_REGF=1): the step's slice as NDMA plain 16-byte loads per
+  // wavefront (scalar base + lane offset, seen by the compiler: it counts their vmcnt itself), written to the ring one
+  // body later with ds_write_b128.  Body k writes step k+2 (loaded in body k-1) into slot (k+2) % 3 -- free since the
+  // barrier of body k-1: step k-1's fragments were read in body k-2 -- and loads step k+3.
+  constexpr bool REGF = (VG_RING_REGF != 0) && F16;
+  static_assert(!REGF || NSLOT == 3, "register path: three slots");
+  f32x4 freg[REGF ? NDMA : 1];
+  auto filt_load = [&](bool second = false) {
+    const bf16x8*& dma_ptr = second ? dma_ptr2 : dma_ptr1;
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) freg[j] = *(const f32x4*)((const char*)dma_ptr + dma_src[j]);
+    dma_ptr += wstep;
+  };
+  auto filt_store = [&](int slot) {
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) lds[RING0 + slot * SLOTU + dma_dst[j] + lane] = freg[j];
+  };
 
   // ---- per-lane operand bases (units)
   int base_a[FC], base_b[FP];
@@ -409,8 +430,14 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
   // ---- prologue: first patch buffer, ring slots 0..2, fragments of step 0
   dma_ptr1 += (size_t)c_begin * NA * wstep;
   dma_ptr2 += (size_t)c_begin * NB2 * wstep;
+  if constexpr (REGF) {
+    filt_load(); filt_store(0);
+    filt_load(); filt_store(1);
+    filt_load();                                     // step 2 stays in registers until body 0
+  } else {
 #pragma unroll
-  for (int i = 0; i < NSLOT; ++i) dma_next(i);
+    for (int i = 0; i < NSLOT; ++i) dma_next(i);
+  }
   stage_load(c_begin * 16);
   stage_store(0);
   wait_vmcnt<0>();
@@ -509,6 +536,12 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
 #define VG_RING_PLACE 0
 #endif
       auto mem_block = [&]() {
+        if constexpr (REGF) {
+          if (!(abl & 1)) {
+            filt_store(slot == 0 ? 2 : slot - 1);                                  // step k+2 -> slot (k+2) % 3
+            filt_load(TWO && (s + NSLOT) % NSTEP >= NA);                           // step k+3
+          }
+        } else
         if (!(abl & 1)) dma_next(slot, TWO && (s + NSLOT) % NSTEP >= NA);          // step k+NSLOT into the slot read during body k-1
         if (ld && !(abl & 4)) {
           if constexpr (MODE == R_FWD) stage_load(ch * 16 + (s == 0 ? 8 : 16));
@@ -573,6 +606,9 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
       // bodies from the one that issued them (they follow that body's DMA; hipcc itself waits for them where the
       // registers are used)
       const bool ldw = (MODE == R_FWD) ? ((s >= 0 && s < NSLOT - 1) || (s >= 13 && s < 13 + NSLOT - 1)) : (s >= 0 && s < NSLOT - 1);
+      if constexpr (REGF) {
+        // every vector-memory instruction is the compiler's: it waits where a register is used
+      } else
       if (abl & (8 | 4 | 1)) {                                      // ablations change what is in flight: drain or skip
         if (!(abl & 8)) wait_vmcnt<0>();
       } else if (ldw) wait_vmcnt<(NSLOT - 2) * NDMA + NL>(); else wait_vmcnt<(NSLOT - 2) * NDMA>();

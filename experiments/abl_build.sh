@@ -5,6 +5,7 @@
 #   wx:   wgrad_bf16split.hip, -DVG_WX_ABL=<bits>
 #   tfwd: conv_thin_fwd.hip,   -DVG_TF_ABL=<bits>
 #   twg:  conv_thin_wgrad.hip, -DVG_TWG_ABL=<bits>
+# VG_ABL_EXTRA="-DVG_RING_REGF=1" abl_build.sh ring 512   (512: no ablation bit -- a full kernel with the extra defines)
 set -e
 cd "$(dirname "$0")/.."
 C=disentangle_mlp_amd/csrc
@@ -19,7 +20,7 @@ esac
 mkdir -p experiments/abl
 OBJS=$(ls $C/build/*.o | grep -v "/$SRC.o")
 for bits in "$@"; do
-  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -I$C -Wno-unused-result -mllvm -pragma-unroll-threshold=131072 -D$DEF=$bits -c $C/$SRC.hip -o experiments/abl/${which}_$bits.o &&
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -I$C -Wno-unused-result -mllvm -pragma-unroll-threshold=131072 -D$DEF=$bits $VG_ABL_EXTRA -c $C/$SRC.hip -o experiments/abl/${which}_$bits.o &&
     /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o experiments/abl/libabl_${which}_$bits.so experiments/abl/${which}_$bits.o $OBJS ) &
 done
 wait

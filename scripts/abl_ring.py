@@ -32,6 +32,12 @@ with ops.packed_filter_scope():
         w = 0.05 * torch.randn(*((co, ci, 5, 5) if kind == "fwd" else (ci, co, 5, 5)), device="cuda")
         fn = (lambda: ops.conv5x5_fwd(x, w, None, 2)) if kind == "fwd" else (lambda: ops.convT5x5_fwd(x, w, None, 2))
         out.append(f"{kind} {timeit(fn)*1e3:7.1f} us")
+        if bits in (0, 512):     # full kernels (512: a build with extra defines): a structural check against the vendor convolution
+            import torch.nn.functional as F
+            ref = F.conv2d(x, w, None, 2, 2) if kind == "fwd" else F.conv_transpose2d(x, w, None, 2, 2, 1)
+            err = float((fn() - ref).abs().max() / ref.abs().max())
+            out[-1] += f" (vs vendor fp32 conv {err:.1e})"
+            assert err < 1e-4, err
         # the same launch reading its input through a BatchNorm + ReLU (the forward launches of a fused chain)
         sc, sh = 0.5 + torch.rand(ci, device="cuda"), torch.randn(ci, device="cuda")
         fa = (lambda: ops.conv5x5_fwd(x, w, None, 2, in_affine=(sc, sh, 1))) if kind == "fwd" else (lambda: ops.convT5x5_fwd(x, w, None, 2, in_affine=(sc, sh, 1)))
