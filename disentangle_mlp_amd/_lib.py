@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvaegan_hip.so")
-ABI_VERSION = 4      # VG_ABI_VERSION of include/vaegan_hip.h this binding was written against
+ABI_VERSION = 5      # VG_ABI_VERSION of include/vaegan_hip.h this binding was written against
 
 _P, _I, _F, _Z = c_void_p, c_int, c_float, c_size_t
 
@@ -31,6 +31,9 @@ SIGNATURES = {
     "vg_conv5x5_fwd_packed_stats": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "vg_conv5x5_packed_bf16split_bytes": (_Z, [_I, _I, _I]),
     "vg_conv5x5_pack_bf16split": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "vg_gemm_nt_f16x3_workspace_bytes": (_Z, [_I, _I, _I]),
+    "vg_gemm_nt_f16x3": (_I, [_P, _P, _P, _P, _I, _I, _I, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long, _P, _P,
+                              _P, _Z, _P]),
     "vg_absmax": (_I, [_P, _Z, _P, _P]),
     "vg_absmax_affine": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "vg_absmax_multi": (_I, [_P, _I, _P]),

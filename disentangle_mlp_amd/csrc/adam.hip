@@ -22,6 +22,7 @@ struct AdamPack {
   float* m[AMAX];
   float* v[AMAX];
   unsigned long long n[AMAX];
+  unsigned* amax[AMAX];               // per tensor, may be NULL: max |p| after the update is added here (atomic max)
   unsigned first_block[AMAX + 1];     // prefix sums of ceil(n / ACHUNK)
   int count;
 };
@@ -67,6 +68,9 @@ __global__ __launch_bounds__(ANT) void adam_multi_kernel(AdamPack A, float omb1,
   float* __restrict__ m = A.m[t];
   float* __restrict__ v = A.v[t];
   const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+  // bound of max |p| for the fp16-plane GEMMs that read this weight next (VgAdamTensor::amax): the step that changes the
+  // weight is the one pass that sees every new value anyway -- no separate 134 MB read per weight and iteration
+  unsigned am = 0;
   if (vec) {
     const unsigned long long end4 = base + ((end - base) & ~3ULL);
     for (unsigned long long i = base + 4ULL * threadIdx.x; i < end4; i += 4ULL * ANT) {
@@ -78,15 +82,23 @@ __global__ __launch_bounds__(ANT) void adam_multi_kernel(AdamPack A, float omb1,
         float pj = pv[j], mj = mv[j], vj = vv[j];
         adam_one(pj, gv[j], mj, vj, omb1, b2, omb2, step_size, bc2s, eps);
         pv[j] = pj; mv[j] = mj; vv[j] = vj;
+        am = max(am, abs_bits(pj));
       }
       *reinterpret_cast<f32x4*>(p + i) = pv;
       *reinterpret_cast<f32x4*>(m + i) = mv;
       *reinterpret_cast<f32x4*>(v + i) = vv;
     }
-    for (unsigned long long i = end4 + threadIdx.x; i < end; i += ANT) adam_one(p[i], g[i], m[i], v[i], omb1, b2, omb2, step_size, bc2s, eps);
+    for (unsigned long long i = end4 + threadIdx.x; i < end; i += ANT) {
+      adam_one(p[i], g[i], m[i], v[i], omb1, b2, omb2, step_size, bc2s, eps);
+      am = max(am, abs_bits(p[i]));
+    }
   } else {
-    for (unsigned long long i = base + threadIdx.x; i < end; i += ANT) adam_one(p[i], g[i], m[i], v[i], omb1, b2, omb2, step_size, bc2s, eps);
+    for (unsigned long long i = base + threadIdx.x; i < end; i += ANT) {
+      adam_one(p[i], g[i], m[i], v[i], omb1, b2, omb2, step_size, bc2s, eps);
+      am = max(am, abs_bits(p[i]));
+    }
   }
+  if (A.amax[t]) block_amax_atomic<ANT>(am, A.amax[t]);      // (t is uniform over the workgroup)
 }
 
 }  // namespace
@@ -108,6 +120,7 @@ int adam_launch(const VgAdamTensor* tensors, int count, double beta1, double bet
       if (nb > 0x3fffffffULL - blocks) return VG_ERR_BAD_ARG;
       const int k = A.count++;
       A.p[k] = T.p; A.g[k] = T.g; A.m[k] = T.m; A.v[k] = T.v; A.n[k] = T.n;
+      A.amax[k] = reinterpret_cast<unsigned*>(T.amax);
       A.first_block[k] = blocks;
       blocks += (unsigned)nb;
     }

@@ -70,15 +70,22 @@ template <int NP, bool F16>
 __device__ __forceinline__ void split_planes16(float* v, f32x4* out) {
   if constexpr (F16) {
     static_assert(NP == 2, "fp16 planes: hi + lo");
-    f16x8 hi, lo;
+    // Two elements at a time, as 2-wide vectors: v_cvt_pk_f16_f32 (round to nearest even, two floats -> one packed
+    // register, no separate pack), v_pk_add_f32 for the residual -- 2.5 VALU per element where the scalar form
+    // (cvt, cvt back, sub, and a cvt_pk each for packing hi and lo) took 4.  Same roundings: same bits.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    f16x2 hi[4], lo[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const _Float16 h = (_Float16)v[j];          // round to nearest even: |v - h| <= 2^-12 |v|
+    for (int j = 0; j < 4; ++j) {
+      const f32x2 v2 = {v[2 * j], v[2 * j + 1]};
+      const f16x2 h = __builtin_convertvector(v2, f16x2);                 // |v - h| <= 2^-12 |v|
       hi[j] = h;
-      lo[j] = (_Float16)(v[j] - (float)h);        // exact difference, rounded to 11 more bits
+      lo[j] = __builtin_convertvector(v2 - __builtin_convertvector(h, f32x2), f16x2);   // exact difference, 11 more bits
     }
-    out[0] = __builtin_bit_cast(f32x4, hi);
-    out[1] = __builtin_bit_cast(f32x4, lo);
+    struct P4 { f16x2 q[4]; };
+    out[0] = __builtin_bit_cast(f32x4, P4{{hi[0], hi[1], hi[2], hi[3]}});
+    out[1] = __builtin_bit_cast(f32x4, P4{{lo[0], lo[1], lo[2], lo[3]}});
   } else {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {                // hi, (mid,) lo: each plane takes the leading 8 bits of what is left

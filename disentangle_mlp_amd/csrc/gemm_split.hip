@@ -1,0 +1,289 @@
+// Linear layers in the fp16x3 arithmetic (vg_gemm_nt_f16x3) for gfx950: the three GEMMs of nn.Linear's forward /
+// backward on the big layers of the path (encoder 16384 -> 2048, /root/reference/models/model.py:460-471; discriminator
+// lth_features 16384 -> 2048, :402-404; decoder 128 -> 16384, :490-492), where the vendor's fp32 GEMM is bound by the
+// fp32 MFMA (~100-150 TFLOP/s: 62-83 us per launch) and the 134 MB weight could stream in a third of that time:
+//
+//     C[m][n] = sum_k A(m, k) * B(n, k) (+ bias[n]),      A(m, k) = A[m * ars + k * aks],  B(n, k) = B[n * brs + k * bks]
+//
+// with, per operand, either the reduction index contiguous (k stride 1) or the row index contiguous (row stride 1):
+//   forward   y  = x W^T   : A = x  (ars = K,  aks = 1),   B = W (brs = K, bks = 1)
+//   data grad gx = gy W    : A = gy (ars = N', aks = 1),   B = W read as [k_in][n] (brs = 1, bks = K_in)
+//   weight gr gW = gy^T x  : A = gy read as [n][b] (ars = 1, aks = N'),   B = x read as [k][b] (brs = 1, bks = K_in)
+// Same arithmetic as the convolutions (conv_ring.hip): each fp32 operand times an exact power of two
+// from a device-side bound of its largest magnitude, split into fp16 hi + lo, the products lo*hi, hi*lo, hi*hi on
+// v_mfma_f32_32x32x16_f16, fp32 accumulation, the two scales undone on the accumulators.  (Rounds 2-3 had this kernel
+// with three bf16 planes -- 6 MFMAs per multiply, matrix-bound, level with the vendor library -- and removed it; at 3
+// MFMAs the weight stream is the bound.)
+//
+// One workgroup = 4 wavefronts (2 x 2 of 64 x 64: 8 fragment reads per 12 MFMAs) owns a 128 x 128 output tile and a
+// slice of the reduction (K split over workgroups; partial tiles go to slabs summed in a fixed order: no atomics).  A
+// stage = 32 reduction indices: a thread stages two 8-index units of A and two of B -- two 16-byte loads each where the
+// reduction index is contiguous, eight 4-byte loads (a row apart; consecutive lanes = consecutive rows, coalesced)
+// where it is not -- G_PD stages ahead in registers, splits them into planes and writes two 16-byte LDS units each
+// ([plane][k-block][row], k-blocks padded by two units so that the 4 lanes that share a row do not share banks);
+// stages are double-buffered in LDS, ONE barrier per stage.  Plain loads only: hipcc counts vmcnt itself.
+#include "common.hpp"
+#include "vaegan_hip.h"
+
+namespace {
+
+constexpr int GNT = 256, GTM = 128, GTN = 128, GKC = 32;   // threads, tile rows / columns, reduction indices per stage
+constexpr int GPAD = 2;
+constexpr int G_KB = GTM + GPAD;                             // units per k-block (A and B tiles have the same height)
+constexpr int G_PL = 4 * G_KB;                               // units per plane
+constexpr int G_NP = 2;                                      // fp16 hi + lo
+constexpr int G_PD = 3;                                      // register slots: two stages in flight, one being split
+constexpr int G_UA = GTM * 4 / GNT, G_UB = GTN * 4 / GNT;    // staged units per thread: 2 + 2
+static_assert(GTM == GTN && G_UA == 2 && G_UB == 2, "staging map");
+
+// timing experiments only (experiments/abl_build.sh gemm <bits>; results are then wrong): 1 every workgroup streams the B
+// rows of tile 0 / split 0 (cache-resident), 2 the same for A, 4 no plane split (raw bits stored), 8 no MFMAs
+#ifndef VG_GEMM_ABL
+#define VG_GEMM_ABL 0
+#endif
+
+struct GArgs {
+  const float* A;
+  const float* B;
+  const float* bias;
+  float* C;            // ksplit == 1: the output [M][N]; else the slabs [ksplit][M][N]
+  int M, N, K;
+  long ars, aks, brs, bks;
+  int kper;            // reduction indices per split (multiple of GKC)
+  int ksplit;
+  int tiles_m, tiles_n;
+  const float* a_amax; // device: upper bounds of max |A|, max |B|
+  const float* b_amax;
+};
+
+__device__ __forceinline__ void load8(float* r, const float* p, long ks, bool strided) {
+  if (strided) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = p[(size_t)j * ks];
+  } else {
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  }
+}
+
+// AT / BT: the operand's ROW index is the contiguous one (reduction index strided)
+template <bool AT, bool BT>
+__global__ __launch_bounds__(GNT, 2) void gemm_nt_f16x3_kernel(GArgs G) {
+  constexpr int BUFU = G_NP * 2 * G_PL;
+  __shared__ f32x4 lds[2 * BUFU];                      // [buffer][A planes | B planes][k-block][row]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kb = lane >> 5, l32 = lane & 31;
+  const int wm = wid & 1, wn = wid >> 1;                // 2 x 2 wavefronts: 64 rows x 64 columns each
+  // workgroup -> (row tile, column tile, split).  Splits are dealt to the XCDs (blockIdx round-robins over the 8 of
+  // them): the workgroups of one split -- they read the same reduction slice of A -- follow each other through one L2,
+  // row tiles of one column tile (same slice of B) back to back.
+  int mt, nt, split;
+  {
+    const int per = G.tiles_m * G.tiles_n;             // workgroups per split
+    int bid = blockIdx.x;
+    if (G.ksplit % 8 == 0) {
+      const int xcd = bid & 7, j = bid >> 3;
+      split = xcd + 8 * (j / per);
+      bid = j % per;
+    } else {
+      split = bid / per;
+      bid -= split * per;
+    }
+    nt = bid / G.tiles_m;
+    mt = bid - nt * G.tiles_m;
+  }
+  const int m0 = mt * GTM, n0 = nt * GTN;
+  const int k_begin = split * G.kper, k_end = min(k_begin + G.kper, G.K);
+  const int nst = (k_end - k_begin) / GKC;
+  const float a_scale = f16_scale_of(*G.a_amax), b_scale = f16_scale_of(*G.b_amax);
+
+  // ---- staging map: unit (row, k-block) -> thread.  Reduction contiguous: 4 consecutive lanes cover the 32 indices
+  // (128 B) of a row; row contiguous: consecutive lanes = consecutive rows, the unit's 8 indices a k-stride apart.
+  const float* up[4];      // units 0, 1: A; 2, 3: B
+  int u_dst[4];
+  bool u_ok[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const bool isb = u >= 2, tr = isb ? BT : AT;
+    const int e = tid + GNT * (u & 1);
+    const int row = tr ? (e & (GTM - 1)) : (e >> 2), kblk = tr ? (e >> 7) : (e & 3);
+    const int r0 = isb ? n0 : m0, rmax = isb ? G.N : G.M;
+    const long rs = isb ? G.brs : G.ars, ks = isb ? G.bks : G.aks;
+    u_ok[u] = (r0 + row) < rmax;
+    const bool cached = (VG_GEMM_ABL & (isb ? 1 : 2)) != 0;
+    up[u] = (isb ? G.B : G.A) + (size_t)min((cached ? 0 : r0) + row, rmax - 1) * rs + (size_t)((cached ? 0 : k_begin) + kblk * 8) * ks;
+    u_dst[u] = (isb ? G_NP * G_PL : 0) + kblk * G_KB + row;
+  }
+
+  float rg[G_PD][4][8];
+  auto load_stage = [&](int slot, int st) {            // st: stage index within this split
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      load8(rg[slot][u], up[u] + (size_t)st * GKC * (u >= 2 ? G.bks : G.aks), u >= 2 ? G.bks : G.aks, u >= 2 ? BT : AT);
+  };
+  // one staged unit: scale, split into hi / lo, two LDS units
+  auto piece = [&](int slot, int u, f32x4* base) {
+    float* v = rg[slot][u];
+    // rows beyond M / N (clamped re-reads of the last row) are multiplied by zero: they only ever meet output rows /
+    // columns that are not stored
+    const float sc = u_ok[u] ? (u >= 2 ? b_scale : a_scale) : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= sc;
+    f32x4 pl[G_NP];
+    if constexpr ((VG_GEMM_ABL & 4) != 0) {
+      pl[0] = f32x4{v[0], v[1], v[2], v[3]};
+      pl[1] = f32x4{v[4], v[5], v[6], v[7]};
+    } else
+    split_planes16<G_NP, true>(v, pl);
+    base[u_dst[u]] = pl[0];
+    base[u_dst[u] + G_PL] = pl[1];
+  };
+  auto read_frags = [&](bf16x8 (&av)[2][G_NP], bf16x8 (&bv)[2][G_NP], const f32x4* base, int s2) {
+#pragma unroll
+    for (int p = 0; p < G_NP; ++p)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        av[g][p] = __builtin_bit_cast(bf16x8, base[p * G_PL + (2 * s2 + kb) * G_KB + wm * 64 + g * 32 + l32]);
+        bv[g][p] = __builtin_bit_cast(bf16x8, base[(G_NP + p) * G_PL + (2 * s2 + kb) * G_KB + wn * 64 + g * 32 + l32]);
+      }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[g][h][r] = 0.f;
+
+  if (nst > 0) {
+    // stages past the end re-load the last one (never consumed): every register slot always holds valid data
+#pragma unroll
+    for (int j = 0; j < G_PD; ++j) load_stage(j, min(j, nst - 1));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) piece(0, u, lds);
+    __syncthreads();
+    // One stage: 6 groups of 4 MFMAs (2 steps of 16 x the 3 plane products); the split of stage st + 1 (4 units) rides
+    // on the first four groups, the second step's fragments are read during the first step's second group.  `j`: the
+    // register slot that held stage st (compile-time: the loop below is unrolled by G_PD with no branch inside -- with
+    // a per-stage `if (st < nst)` hipcc's vmcnt bookkeeping lost track across the joins and drained every load in
+    // front of the next stage's address arithmetic).
+    auto stage = [&](int st, int j) {
+      const int buf = st & 1;
+      const f32x4* base = lds + buf * BUFU;
+      f32x4* nxt = lds + (buf ^ 1) * BUFU;           // stage st + 1 (loaded G_PD - 1 stages ago) goes here --
+                                                     // after the last stage too (a re-store nobody reads): no branch
+      bf16x8 av0[2][G_NP], bv0[2][G_NP], av1[2][G_NP], bv1[2][G_NP];
+      load_stage(j, min(st + G_PD, nst - 1));        // slot j held stage st: split during stage st - 1
+      read_frags(av0, bv0, base, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      int grp = 0;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int sum = G_NP - 1; sum >= 0; --sum)
+#pragma unroll
+          for (int pa = sum; pa >= 0; --pa) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+              for (int h = 0; h < 2; ++h)
+                if constexpr ((VG_GEMM_ABL & 8) == 0)
+                acc[g][h] = s2 == 0 ? mfma_split16<true>(av0[g][pa], bv0[h][sum - pa], acc[g][h])
+                                    : mfma_split16<true>(av1[g][pa], bv1[h][sum - pa], acc[g][h]);
+            if constexpr ((VG_GEMM_ABL & 16) != 0) {       // timing experiment: the split rides on the LAST four groups
+              if (grp >= 2) piece((j + 1) % G_PD, grp - 2, nxt);
+            } else
+            if (grp < 4) piece((j + 1) % G_PD, grp, nxt);
+            if (grp == 1) read_frags(av1, bv1, base, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            ++grp;
+          }
+      __syncthreads();
+    };
+    int st = 0;
+    for (; st + G_PD <= nst; st += G_PD) {
+#pragma unroll
+      for (int j = 0; j < G_PD; ++j) stage(st + j, j);
+    }
+    // the last nst % G_PD stages (slots 0, 1 in turn: the loop above left at a multiple of G_PD)
+    if (st < nst) stage(st, 0);
+    if (st + 1 < nst) stage(st + 1, 1);
+    static_assert(G_PD == 3, "tail above");
+  }
+
+  // ---- epilogue: undo the two scales (exact), C (or this split's slab) row-major [M][N]; the bias goes in with split 0
+  const float ua = f16_unscale_of(*G.a_amax), ub = f16_unscale_of(*G.b_amax);
+  float* out = G.C + (G.ksplit > 1 ? (size_t)split * G.M * G.N : 0);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int n = n0 + wn * 64 + h * 32 + l32;
+    const float bvv = (G.bias && split == 0 && n < G.N) ? G.bias[n] : 0.f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int r16 = 0; r16 < 16; ++r16) {
+        const int m = m0 + wm * 64 + g * 32 + acc_row(r16, lane);
+        if (m < G.M && n < G.N) out[(size_t)m * G.N + n] = acc[g][h][r16] * ua * ub + bvv;
+      }
+  }
+}
+
+#ifndef G_TARGET_WGS
+#define G_TARGET_WGS 256
+#endif
+// K split: as many splits as keep >= 8 stages each and bring the grid to about G_TARGET_WGS workgroups
+int gemm_ksplit(int M, int N, int K) {
+  const long tiles = (long)cdiv(M, GTM) * cdiv(N, GTN);
+  int ks = 1;
+  while (tiles * ks * 2 <= G_TARGET_WGS && K % (GKC * ks * 2) == 0 && K / (ks * 2) >= 8 * GKC) ks *= 2;
+  return ks;
+}
+
+bool gemm_ok(int M, int N, int K, long ars, long aks, long brs, long bks) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % GKC) return false;
+  if (!((aks == 1 && ars % 4 == 0) || ars == 1)) return false;      // 16-byte loads need aligned rows
+  if (!((bks == 1 && brs % 4 == 0) || brs == 1)) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" size_t vg_gemm_nt_f16x3_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % GKC) return 0;
+  const int ks = gemm_ksplit(M, N, K);
+  return ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
+}
+
+extern "C" int vg_gemm_nt_f16x3(const float* A, const float* B, const float* bias, float* C, int M, int N, int K,
+                                long a_row_stride, long a_k_stride, long b_row_stride, long b_k_stride,
+                                const float* a_amax, const float* b_amax, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+  if (!A || !B || !C || !a_amax || !b_amax) return VG_ERR_BAD_ARG;
+  if (!gemm_ok(M, N, K, a_row_stride, a_k_stride, b_row_stride, b_k_stride)) return VG_ERR_BAD_ARG;
+  if ((a_k_stride == 1 && ((uintptr_t)A & 15)) || (b_k_stride == 1 && ((uintptr_t)B & 15))) return VG_ERR_BAD_ARG;
+  const int ks = gemm_ksplit(M, N, K);
+  if (ks > 1 && (!workspace || workspace_bytes < (size_t)ks * M * N * sizeof(float))) return VG_ERR_WORKSPACE;
+  if ((size_t)M * N > 0x7fffffffUL) return VG_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  GArgs G;
+  G.A = A; G.B = B; G.bias = bias; G.C = ks > 1 ? (float*)workspace : C;
+  G.M = M; G.N = N; G.K = K;
+  G.ars = a_row_stride; G.aks = a_k_stride; G.brs = b_row_stride; G.bks = b_k_stride;
+  G.kper = K / ks; G.ksplit = ks;
+  G.tiles_m = cdiv(M, GTM); G.tiles_n = cdiv(N, GTN);
+  G.a_amax = a_amax; G.b_amax = b_amax;
+  const long grid = (long)G.tiles_m * G.tiles_n * ks;
+  if (grid > 0x7fffffffL) return VG_ERR_BAD_ARG;
+  const bool at = a_k_stride != 1, bt = b_k_stride != 1;
+  const dim3 g((unsigned)grid), b(GNT);
+  if (at && bt) hipLaunchKernelGGL((gemm_nt_f16x3_kernel<true, true>), g, b, 0, st, G);
+  else if (at) hipLaunchKernelGGL((gemm_nt_f16x3_kernel<true, false>), g, b, 0, st, G);
+  else if (bt) hipLaunchKernelGGL((gemm_nt_f16x3_kernel<false, true>), g, b, 0, st, G);
+  else hipLaunchKernelGGL((gemm_nt_f16x3_kernel<false, false>), g, b, 0, st, G);
+  VG_CHECK_LAUNCH();
+  if (ks > 1) return vg_internal_wgrad_reduce((const float*)workspace, C, M * N, ks, st);   // fixed-order sum of the slabs
+  return 0;
+}

@@ -154,9 +154,11 @@ DEFER_WGRAD = __import__("os").environ.get("VG_DEFER_WGRAD", "1") != "0"      # 
 
 
 class LinearFn(Function):
-    """nn.Linear (model.py:460-471, 402-408, 490-492) on the vendor fp32 GEMMs (algorithm table:
-    tuned_gemms.py).  Exists for `deferred_wgrad()`: inside it the weight gradient of a layer with >= 2^20 weights is
-    batched over its passes.  (Round 2's split-bf16 GEMM for these layers was removed: DESIGN.md section 4.5.)"""
+    """nn.Linear (model.py:460-471, 402-408, 490-492).  Layers with >= 2^20 weights run on this package's fp16x3 GEMM
+    under the default arithmetic (ops.linear_*; a GEMM whose reduction length is not a multiple of 32 -- the weight
+    gradient at batches that are not -- goes to the vendor library), everything else on the vendor fp32 GEMMs (SURVEY.md
+    K7; algorithm table: tuned_gemms.py).  Inside `deferred_wgrad()` the weight gradient of a layer with >= 2^20 weights
+    is batched over its passes."""
 
     @staticmethod
     def forward(ctx, x, w, bias, bias_grad=BIAS_GRAD_COMPUTE):
@@ -167,6 +169,8 @@ class LinearFn(Function):
         ctx.defer = dctx if (dctx is not None and ctx.needs_input_grad[1] and w.numel() >= DEFER_MIN_WEIGHTS) else None
         if ctx.defer is not None:
             dctx.pending[id(w)] = dctx.pending.get(id(w), 0) + 1
+        if ops.linear_split_ok(x.shape[1], w.numel()):
+            return ops.linear_fwd(x, w, bias)
         return torch.nn.functional.linear(x, w, bias)
 
     @staticmethod
@@ -176,7 +180,7 @@ class LinearFn(Function):
         gy = gy.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = gy @ w
+            gx = ops.linear_dgrad(gy, w) if ops.linear_split_ok(gy.shape[1], w.numel()) else gy @ w
         if ctx.needs_input_grad[2] and ctx.bias_grad != BIAS_GRAD_ZERO:      # (a bias that feeds a BatchNorm1d: no gradient)
             gb = gy.sum(0)
         if ctx.needs_input_grad[1]:
@@ -193,9 +197,12 @@ class LinearFn(Function):
                         wg, wx = torch.cat([p[0] for p in pairs]), torch.cat([p[1] for p in pairs])
             if wg is not None:
                 prev = _acc_get(ctx.acc, id(w))
+                split = ops.linear_split_ok(wg.shape[0], w.numel())
                 if prev is None:
-                    gw = wg.t() @ wx
+                    gw = ops.linear_wgrad(wg, wx) if split else wg.t() @ wx
                     _acc_put(ctx.acc, id(w), gw)
+                elif split:
+                    prev.add_(ops.linear_wgrad(wg, wx))
                 else:
                     prev.addmm_(wg.t(), wx)                  # the layer's second use: added in the GEMM's epilogue
         return gx, gw, gb, None

@@ -318,7 +318,7 @@ class Encoder_celeba(nn.Module):
     def forward(self, x, eps=None):
         bs = x.size(0)
         feat = self.features(x)
-        return self.reparameterize(feat.view(bs, -1), eps)
+        return self.reparameterize(ops.keep_amax(feat, feat.view(bs, -1)), eps)
 
 
 class Generator_celeba(nn.Module, _DecoderMixin):
@@ -351,7 +351,8 @@ class Discriminator_celeba(nn.Module):
 
     def forward(self, x):
         bs = x.size(0)
-        feat = self.lth_features(self.convs(x).view(bs, -1))
+        c = self.convs(x)
+        feat = self.lth_features(ops.keep_amax(c, c.view(bs, -1)))
         p = self.sigmoid_output(feat)
         return p.squeeze(), feat.squeeze()
 
@@ -360,7 +361,8 @@ class Discriminator_celeba(nn.Module):
         mean runs over -- the global batch under data parallelism) with the head -- Linear(2048 -> 1) + Sigmoid -- and the
         loss in ONE kernel each way.  Returns (p, features, bce)."""
         bs = x.size(0)
-        feat = self.lth_features(self.convs(x).view(bs, -1))
+        c = self.convs(x)
+        feat = self.lth_features(ops.keep_amax(c, c.view(bs, -1)))
         lin = self.sigmoid_output[0]
         if not FUSE_HEAD_BCE or lin._forward_hooks or lin._forward_pre_hooks or self.sigmoid_output[1]._forward_hooks:
             p = self.sigmoid_output(feat).squeeze()              # hooked head: module by module

@@ -179,6 +179,14 @@ def set_amax(t, slot, in_affine=None):
     return slot
 
 
+def keep_amax(src, view):
+    """``view`` is a reshape of ``src`` (same elements): it inherits the bound a producer attached to ``src``."""
+    known = getattr(src, "_vg_amax", None)
+    if known is not None and known[0] == src._version and known[1] is None:
+        view._vg_amax = (view._version, None, known[2])
+    return view
+
+
 def amax_of(t, in_affine=None):
     """Bound of max |t| -- of max |act(t * scale[c] + shift[c])| with ``in_affine`` = (scale, shift, act[, bound]) -- as a
     one-element device tensor: the one a producer attached, the 4th element of ``in_affine``, or one pass over t."""
@@ -216,6 +224,7 @@ def conv_runs_split(op, cin, cout=None, stride=None):
 
 
 _pack_scope_depth = 0
+_wbound_cache = {}    # Linear weights: data_ptr -> (version, shape, bound slot); lives and dies with the pack cache's entries
 _pack_cache = {}      # (data_ptr, transposed, stride, shape) -> [valid, version, packed tensor]
 _pack_scratch = {}    # (device, stream, numel) -> tensor, for un-cached packs
 _PACK_CACHE_MAX = 64  # entries (a beta-VAE-GAN iteration uses 21); beyond it the cache is rebuilt
@@ -255,11 +264,15 @@ def invalidate_packed_filters(params=None):
     if params is None:
         for ent in _pack_cache.values():
             ent[0] = False
+        _wbound_cache.clear()
         return
     ptrs = {p.data_ptr() for p in params if p.dim() == 4}
     for key, ent in _pack_cache.items():
         if key[0] in ptrs:
             ent[0] = False
+    for p in params:
+        if p.dim() == 2:
+            _wbound_cache.pop(p.data_ptr(), None)
 
 
 def _packed_filter(lib, w, cout, cin, transposed, stride):
@@ -575,6 +588,83 @@ def conv5x5_wgrad(x, gy, stride, out=None, in_affine=None, affine_on_gy=False, a
         check(lib.vg_conv5x5_wgrad(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout, stride,
                                    ws.data_ptr(), ws.numel(), acc, _stream()), "vg_conv5x5_wgrad")
     return dw
+
+
+# ------------------------------------------------------------------- Linear layers
+# The Linear GEMMs of the big layers (16384 <-> 2048 / 512, 128 -> 16384: model.py:460-471, 402-408, 490-492) on this
+# package's fp16x3 GEMM (csrc/gemm_split.hip) under the default arithmetic; under the opt-in arithmetics, for small
+# layers and for reductions that are not a multiple of 32 (the weight gradient at such batches) they stay on the vendor
+# fp32 GEMM.  VG_LINEAR_SPLIT=0 (or ops.LINEAR_SPLIT = False): vendor GEMMs everywhere.
+LINEAR_SPLIT = os.environ.get("VG_LINEAR_SPLIT", "1") != "0"
+LINEAR_SPLIT_MIN_WEIGHTS = 1 << 20
+
+
+def linear_split_ok(reduction, nweights):
+    return LINEAR_SPLIT and _f16() and reduction % 32 == 0 and nweights >= LINEAR_SPLIT_MIN_WEIGHTS
+
+
+_wbound_emitted = {}      # data_ptr -> (version, shape, bound): what the optimizer step that last wrote the weight emitted
+
+
+def set_weight_bound(w, bound):
+    """``bound`` (one-element device tensor) holds max |w| as of now -- HipAdam's step emits it (VgAdamTensor.amax).
+    Valid until the next torch-side in-place write (the version counter) or the next call for this weight."""
+    _wbound_emitted[w.data_ptr()] = (w._version, tuple(w.shape), bound)
+
+
+def weight_bound(w):
+    """Bound of max |w| of a Linear weight: the one the optimizer step emitted when it wrote the weight; failing that,
+    inside a `packed_filter_scope`, measured once per weight version (the scope's owner invalidates after optimizer
+    steps, as for the packed filters), otherwise per call."""
+    ent = _wbound_emitted.get(w.data_ptr())
+    if ent is not None and ent[0] == w._version and ent[1] == tuple(w.shape):
+        return ent[2]
+    if _pack_scope_depth > 0:
+        ent = _wbound_cache.get(w.data_ptr())
+        if ent is not None and ent[0] == w._version and ent[1] == tuple(w.shape):
+            return ent[2]
+    slot = _amax_slot(w.device)          # a fresh (zeroed) slot: the bound follows the weights down as well as up
+    check(_lib.load().vg_absmax(w.data_ptr(), w.numel(), slot.data_ptr(), _stream()), "vg_absmax")
+    if _pack_scope_depth > 0:
+        _wbound_cache[w.data_ptr()] = (w._version, tuple(w.shape), slot)
+    return slot
+
+
+def _gemm_nt(A, B, bias, C, M, N, K, ars, aks, brs, bks, a_amax, b_amax):
+    lib = _lib.load()
+    need = lib.vg_gemm_nt_f16x3_workspace_bytes(M, N, K)
+    ws = workspace(need, A.device) if need else None
+    check(lib.vg_gemm_nt_f16x3(A.data_ptr(), B.data_ptr(), _ptr(bias), C.data_ptr(), M, N, K, ars, aks, brs, bks,
+                               a_amax.data_ptr(), b_amax.data_ptr(), _ptr(ws), ws.numel() if need else 0, _stream()),
+          "vg_gemm_nt_f16x3")
+    return C
+
+
+def linear_fwd(x, w, bias):
+    """y = x W^T + bias (nn.Linear forward, model.py:460-471): x (M, K), w (N, K)."""
+    _req(x, "x"), _req(w, "w")
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    return _gemm_nt(x, w, bias, y, M, N, K, K, 1, K, 1, amax_of(x), weight_bound(w))
+
+
+def linear_dgrad(gy, w):
+    """gx = gy W: gy (M, N), w (N, K) -> (M, K); the reduction runs over N, W is read with its row index contiguous."""
+    _req(gy, "gy"), _req(w, "w")
+    M, N = gy.shape
+    K = w.shape[1]
+    gx = torch.empty((M, K), dtype=torch.float32, device=gy.device)
+    return _gemm_nt(gy, w, None, gx, M, K, N, N, 1, 1, K, amax_of(gy), weight_bound(w))
+
+
+def linear_wgrad(gy, x):
+    """gW = gy^T x: gy (M, N), x (M, K) -> (N, K); the reduction runs over the batch M (both operands strided)."""
+    _req(gy, "gy"), _req(x, "x")
+    M, N = gy.shape
+    K = x.shape[1]
+    gw = torch.empty((N, K), dtype=torch.float32, device=gy.device)
+    return _gemm_nt(gy, x, None, gw, N, K, M, 1, N, 1, K, amax_of(gy), amax_of(x))
 
 
 def channel_sum(g):

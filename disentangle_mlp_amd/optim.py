@@ -14,13 +14,13 @@ import math
 import torch
 from torch import optim
 
-from . import _lib
+from . import _lib, ops
 from ._lib import check
 
 
 class _AdamTensor(ctypes.Structure):
     _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
-                ("n", ctypes.c_size_t)]
+                ("n", ctypes.c_size_t), ("amax", ctypes.c_void_p)]
 
 
 class HipAdam(optim.Adam):
@@ -39,6 +39,11 @@ class HipAdam(optim.Adam):
         self._captured = []       # per captured step() call: the parameters it stepped (host bookkeeping of a replay)
         self._debt = 0            # replays whose host-side step counts have not been added yet (flushed lazily)
         self.state_generation = 0 # bumped by load_state_dict: captured graphs point at the moment tensors of one generation
+        # max |w| of the big Linear weights, emitted by the step itself (VgAdamTensor.amax) for the fp16x3 GEMMs that read
+        # the weight next: one persistent fp32 word per weight (persistent: a replayed step writes where the next replay's
+        # GEMMs read), zeroed in front of every step
+        self._bound_of = {}       # parameter -> index into self._bounds
+        self._bounds = None
         self.register_state_dict_pre_hook(lambda opt: opt._flush_replays())
 
     def _native_ok(self, group):
@@ -139,6 +144,9 @@ class HipAdam(optim.Adam):
             raise RuntimeError("HipAdam: construct with capturable=True to capture its step in a HIP graph")
         if not capturing:
             self._flush_replays()
+        bounds = self._weight_bounds()
+        if bounds is not None:
+            bounds.zero_()
         for gi, group in enumerate(self.param_groups):
             beta1, beta2 = group["betas"]
             by_step = {}
@@ -162,7 +170,9 @@ class HipAdam(optim.Adam):
             for step, items in by_step.items():
                 arr = (_AdamTensor * len(items))()
                 for i, (p, g, m, v) in enumerate(items):
-                    arr[i] = _AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel())
+                    bi = self._bound_of.get(p) if bounds is not None else None
+                    arr[i] = _AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+                                         None if bi is None else bounds[bi:bi + 1].data_ptr())
                 if self.device_scalars:
                     step_dev, scalars = self._device_state(gi, items[0][0].device)
                     # an eager step also stores its count in the device counter: replays may follow it
@@ -177,4 +187,34 @@ class HipAdam(optim.Adam):
                 bc2_sqrt = math.sqrt(1.0 - beta2 ** step)
                 check(lib.vg_adam_step(arr, len(items), float(group["lr"]), float(beta1), float(beta2), float(group["eps"]),
                                        bc1, bc2_sqrt, stream), "vg_adam_step")
+        if bounds is not None:
+            for p, bi in self._bound_of.items():
+                if p.grad is not None:
+                    ops.set_weight_bound(p, bounds[bi:bi + 1])
         return None
+
+    @torch.no_grad()
+    def refresh_weight_bounds(self):
+        """Measure max |w| of the big Linear weights again, into the same device words (after weights were written by
+        something other than `step` -- a checkpoint copied in place under a captured iteration, whose GEMMs read these
+        words)."""
+        bounds = self._weight_bounds()
+        if bounds is None:
+            return
+        bounds.zero_()
+        lib, stream = _lib.load(), torch.cuda.current_stream().cuda_stream
+        for p, bi in self._bound_of.items():
+            slot = bounds[bi:bi + 1]
+            check(lib.vg_absmax(p.data_ptr(), p.numel(), slot.data_ptr(), stream), "vg_absmax")
+            ops.set_weight_bound(p, slot)
+
+    def _weight_bounds(self):
+        """The bounds tensor (one word per Linear weight the fp16x3 GEMM takes), or None when there is none."""
+        if self._bounds is None:
+            big = [p for g in self.param_groups for p in g["params"]
+                   if p.dim() == 2 and p.is_cuda and p.numel() >= ops.LINEAR_SPLIT_MIN_WEIGHTS]
+            if not big:
+                return None
+            self._bound_of = {p: i for i, p in enumerate(big)}
+            self._bounds = torch.zeros(len(big), dtype=torch.float32, device=big[0].device)
+        return self._bounds

@@ -821,6 +821,9 @@ class BetaVAEGANTrainer(_GraphedSteps):
         if self._pack_plans is not None:
             with ops.packed_filter_scope():
                 ops.prepack_filters([r for v in self._pack_plans.values() for r in v])
+        for opt in (self.optimizerEG, self.optimizerD):      # (the bounds the captured GEMMs read beside the weights)
+            if isinstance(opt, HipAdam):
+                opt.refresh_weight_bounds()
         return ck["epoch"]
 
 

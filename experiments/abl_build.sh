@@ -5,6 +5,7 @@
 #   wx:   wgrad_bf16split.hip, -DVG_WX_ABL=<bits>
 #   tfwd: conv_thin_fwd.hip,   -DVG_TF_ABL=<bits>
 #   twg:  conv_thin_wgrad.hip, -DVG_TWG_ABL=<bits>
+#   gemm: gemm_split.hip,      -DVG_GEMM_ABL=<bits>
 # VG_ABL_EXTRA="-DVG_RING_REGF=1" abl_build.sh ring 512   (512: no ablation bit -- a full kernel with the extra defines)
 set -e
 cd "$(dirname "$0")/.."
@@ -15,7 +16,8 @@ case $which in
   wx)   SRC=wgrad_bf16split; DEF=VG_WX_ABL ;;
   tfwd) SRC=conv_thin_fwd; DEF=VG_TF_ABL ;;
   twg)  SRC=conv_thin_wgrad; DEF=VG_TWG_ABL ;;
-  *) echo "usage: $0 <ring|wx|tfwd|twg> <bits> ..."; exit 2 ;;
+  gemm) SRC=gemm_split; DEF=VG_GEMM_ABL ;;
+  *) echo "usage: $0 <ring|wx|tfwd|twg|gemm> <bits> ..."; exit 2 ;;
 esac
 mkdir -p experiments/abl
 OBJS=$(ls $C/build/*.o | grep -v "/$SRC.o")

@@ -44,7 +44,7 @@ extern "C" {
  * workspace contract.  vg_version() returns the value the library was built with; a binding must refuse a library
  * whose version is not the header's (the .so files are build products that travel with the working tree: a stale one
  * still exports every old symbol).  3: round 3.  4: round 4 (fp16 planes: VG_PLANES_F16, the *_amax arguments). */
-#define VG_ABI_VERSION 4
+#define VG_ABI_VERSION 5
 int vg_version(void);
 
 /* ---- 5x5 convolutions, padding 2, stride 1 or 2 ----------------------------
@@ -209,6 +209,21 @@ int vg_conv5x5_wgrad_bf16split(const float* x, const float* gy, float* dw, int B
  * x (Cin coefficients) when affine_on_gy == 0, gy (Cout coefficients; the weight gradient of a transposed
  * convolution passes the layer's input there) otherwise.  NULL, NULL, 0, 0: both operands as they are. */
 
+/* ---- Linear layers in the fp16x3 arithmetic (csrc/gemm_split.hip) -------------------------------------------------
+ * C[m][n] = sum_k A(m,k) * B(n,k) (+ bias[n]), A(m,k) = A[m*a_row_stride + k*a_k_stride], B alike; C row-major [M][N].
+ * Per operand either the reduction index is contiguous (k stride 1; row stride % 4 == 0, 16-byte aligned base) or the
+ * row index is (row stride 1).  K % 32 == 0.  One entry point serves nn.Linear (/root/reference/models/model.py:460-471,
+ * 402-408, 490-492; replaces torch.nn.functional.linear and the two backward GEMMs autograd derives from it): forward
+ * y = x W^T (A = x, B = W), data gradient gx = gy W (A = gy, B = W with b_row_stride = 1, b_k_stride = in_features),
+ * weight gradient gW = gy^T x (A = gy with a_row_stride = 1, B = x with b_row_stride = 1; K = batch).  Arithmetic: the
+ * convolutions' fp16x3 (planes = 2 | VG_PLANES_F16 above) -- a_amax[0] >= max |A|, b_amax[0] >= max |B|, DEVICE memory.
+ * Short output grids split the reduction over workgroups: query the workspace (partial tiles, summed in a fixed order;
+ * no atomics -- results are reproducible run to run). */
+size_t vg_gemm_nt_f16x3_workspace_bytes(int M, int N, int K);
+int vg_gemm_nt_f16x3(const float* A, const float* B, const float* bias, float* C, int M, int N, int K,
+                     long a_row_stride, long a_k_stride, long b_row_stride, long b_k_stride,
+                     const float* a_amax, const float* b_amax, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Bounds for the fp16 planes: amax[0] = max(amax[0], max |x|) over n floats -- an atomic maximum on the bit pattern
  * (order-independent; a NaN in x ends up in the bound); the caller zeroes amax[0] first (or keeps accumulating a bound
  * over several tensors).  _affine: over act(x[b][c][hw] * scale[c] + shift[c]) (vg_conv_fusion semantics).  _multi: many
@@ -359,6 +374,9 @@ typedef struct {
   float* m;
   float* v;
   size_t n;
+  /* NULL, or DEVICE memory: amax[0] = max(amax[0], max |p| after the update) -- the bound the fp16x3 Linear GEMMs
+   * (vg_gemm_nt_f16x3) scale this weight by; the caller zeroes it before the step */
+  float* amax;
 } VgAdamTensor;
 int vg_adam_step(const VgAdamTensor* tensors, int count, double lr, double beta1, double beta2, double eps,
                  double bias_correction1, double bias_correction2_sqrt, void* stream);

@@ -1102,3 +1102,79 @@ def test_dot_sigmoid_bce(H, B, K, label, dev_label):
     (l2 * 0.75).backward()
     assert torch.equal(f2.grad, gfeat)
 
+
+
+# ---- Linear layers on the fp16x3 GEMM (csrc/gemm_split.hip; nn.Linear of model.py:460-471, 402-408, 490-492) ----------
+@pytest.mark.parametrize("M,K,N", [(128, 2048, 384),      # whole tiles, K split
+                                   (96, 1024, 224),       # ragged rows and columns (masked)
+                                   (160, 128, 2048),      # the decoder's shape: short reduction, two row tiles
+                                   (32, 4096, 128)])      # one tile, deep reduction split over workgroups
+def test_linear_gemms_fp16x3_vs_fp64(H, M, K, N):
+    """Forward, data gradient and weight gradient of a Linear layer through vg_gemm_nt_f16x3 against fp64 matmuls, at the
+    convolutions' tolerance (relative L2 <= CONV_TOL) and element-wise against the largest output."""
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g) * torch.logspace(-3, 1, K)       # columns spanning four decades
+    w = torch.randn(N, K, generator=g) * 0.02
+    b = torch.randn(N, generator=g)
+    gy = torch.randn(M, N, generator=g) * 1e-4
+    xd, wd, bd, gd = (t.cuda() for t in (x, w, b, gy))
+    cases = [("fwd", H.linear_fwd(xd, wd, bd), x.double() @ w.double().t() + b.double()),
+             ("dgrad", H.linear_dgrad(gd, wd), gy.double() @ w.double())]
+    if M % 32 == 0:
+        cases.append(("wgrad", H.linear_wgrad(gd, xd), gy.double().t() @ x.double()))
+    for name, got, ref in cases:
+        got = got.double().cpu()
+        rel = float((got - ref).norm() / ref.norm())
+        worst = float((got - ref).abs().max() / ref.abs().max())
+        assert rel <= 3e-6 and worst <= 3e-6, (name, rel, worst)
+    # run to run: the K split sums its slabs in a fixed order
+    assert torch.equal(H.linear_fwd(xd, wd, bd), H.linear_fwd(xd, wd, bd))
+
+
+def test_linear_layer_autograd_matches_vendor_gemm(H):
+    """functional.linear (LinearFn) on the fp16x3 GEMM against the same layer on the vendor fp32 GEMM: outputs and all three
+    gradients agree to fp32 rounding (both are fp32-equivalent; neither is the reference)."""
+    from disentangle_mlp_amd import functional as F
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(128, 4096, generator=g).cuda()
+    w0 = (torch.randn(512, 4096, generator=g) * 0.02).cuda()
+    b0 = torch.randn(512, generator=g).cuda()
+    outs = []
+    for split in (True, False):
+        prev, H.LINEAR_SPLIT = H.LINEAR_SPLIT, split
+        try:
+            x, w, b = (t.clone().requires_grad_(True) for t in (x0, w0, b0))
+            y = F.linear(x, w, b)
+            (y * torch.linspace(-1, 1, 512, device="cuda")).sum().backward()
+            outs.append((y.detach(), x.grad, w.grad, b.grad))
+        finally:
+            H.LINEAR_SPLIT = prev
+    assert H.linear_split_ok(4096, w0.numel())
+    for a, b_ in zip(*outs):
+        assert float((a - b_).abs().max() / b_.abs().max()) <= 5e-6
+
+
+def test_adam_step_emits_the_bound_of_big_linear_weights(H):
+    """HipAdam's step leaves max |w| of every Linear weight the fp16x3 GEMM takes (>= 2^20 elements) in a persistent
+    device word (VgAdamTensor.amax): ops.weight_bound returns it -- exactly max |w| -- until the weight is written by
+    something else; a torch-side in-place write falls back to a measurement, refresh_weight_bounds re-measures in place."""
+    from disentangle_mlp_amd.optim import HipAdam
+    g = torch.Generator().manual_seed(11)
+    w = torch.nn.Parameter((torch.randn(1024, 1024, generator=g) * 0.02).cuda())
+    small = torch.nn.Parameter(torch.randn(64, 64, generator=g).cuda())
+    opt = HipAdam([w, small], lr=1e-2)
+    for _ in range(2):
+        w.grad = torch.randn(1024, 1024, generator=g).cuda()
+        small.grad = torch.randn(64, 64, generator=g).cuda()
+        opt.step()
+        b = H.weight_bound(w)
+        assert b.data_ptr() == opt._bounds.data_ptr() and float(b) == float(w.detach().abs().max())
+    with H.packed_filter_scope():                       # survives scope boundaries (a trainer opens one per iteration)
+        assert H.weight_bound(w).data_ptr() == opt._bounds.data_ptr()
+    with torch.no_grad():
+        w.mul_(3.0)                                     # version bump: the emitted bound is stale
+    b2 = H.weight_bound(w)
+    assert b2.data_ptr() != opt._bounds.data_ptr() and float(b2) == float(w.detach().abs().max())
+    opt.refresh_weight_bounds()
+    b3 = H.weight_bound(w)
+    assert b3.data_ptr() == opt._bounds.data_ptr() and float(b3) == float(w.detach().abs().max())
