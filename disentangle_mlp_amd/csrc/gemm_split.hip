@@ -27,14 +27,20 @@
 
 namespace {
 
-constexpr int GNT = 256, GTM = 128, GTN = 128, GKC = 32;   // threads, tile rows / columns, reduction indices per stage
+// G_W8: 8 wavefronts (2 x 4 of 64 x 32) per tile instead of 4 (2 x 2 of 64 x 64): two wavefronts per SIMD on the grids
+// that give every CU one workgroup only (forward / data gradient at batch 128), half the staging per thread
+#ifndef G_W8
+#define G_W8 1
+#endif
+constexpr int GNT = G_W8 ? 512 : 256, GTM = 128, GTN = 128, GKC = 32;   // threads, tile rows / columns, reduction indices per stage
+constexpr int G_HN = G_W8 ? 1 : 2;                           // 32-column fragments per wavefront
 constexpr int GPAD = 2;
 constexpr int G_KB = GTM + GPAD;                             // units per k-block (A and B tiles have the same height)
 constexpr int G_PL = 4 * G_KB;                               // units per plane
 constexpr int G_NP = 2;                                      // fp16 hi + lo
 constexpr int G_PD = 3;                                      // register slots: two stages in flight, one being split
-constexpr int G_UA = GTM * 4 / GNT, G_UB = GTN * 4 / GNT;    // staged units per thread: 2 + 2
-static_assert(GTM == GTN && G_UA == 2 && G_UB == 2, "staging map");
+constexpr int G_NU = GTM * 4 / GNT;                          // staged units per thread and operand: 2 (4 wavefronts) or 1
+static_assert(GTM == GTN && (G_NU == 1 || G_NU == 2), "staging map");
 
 // timing experiments only (experiments/abl_build.sh gemm <bits>; results are then wrong): 1 every workgroup streams the B
 // rows of tile 0 / split 0 (cache-resident), 2 the same for A, 4 no plane split (raw bits stored), 8 no MFMAs
@@ -75,7 +81,8 @@ __global__ __launch_bounds__(GNT, 2) void gemm_nt_f16x3_kernel(GArgs G) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kb = lane >> 5, l32 = lane & 31;
-  const int wm = wid & 1, wn = wid >> 1;                // 2 x 2 wavefronts: 64 rows x 64 columns each
+  const int wm = wid & 1, wn = wid >> 1;                // 2 x 2 wavefronts of 64 x 64, or 2 x 4 of 64 rows x 32 columns
+  const int wcol = wn * 32 * G_HN;
   // workgroup -> (row tile, column tile, split).  Splits are dealt to the XCDs (blockIdx round-robins over the 8 of
   // them): the workgroups of one split -- they read the same reduction slice of A -- follow each other through one L2,
   // row tiles of one column tile (same slice of B) back to back.
@@ -101,13 +108,13 @@ __global__ __launch_bounds__(GNT, 2) void gemm_nt_f16x3_kernel(GArgs G) {
 
   // ---- staging map: unit (row, k-block) -> thread.  Reduction contiguous: 4 consecutive lanes cover the 32 indices
   // (128 B) of a row; row contiguous: consecutive lanes = consecutive rows, the unit's 8 indices a k-stride apart.
-  const float* up[4];      // units 0, 1: A; 2, 3: B
-  int u_dst[4];
-  bool u_ok[4];
+  const float* up[2 * G_NU];      // units [0, G_NU): A; [G_NU, 2 G_NU): B
+  int u_dst[2 * G_NU];
+  bool u_ok[2 * G_NU];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const bool isb = u >= 2, tr = isb ? BT : AT;
-    const int e = tid + GNT * (u & 1);
+  for (int u = 0; u < 2 * G_NU; ++u) {
+    const bool isb = u >= G_NU, tr = isb ? BT : AT;
+    const int e = tid + GNT * (u % G_NU);
     const int row = tr ? (e & (GTM - 1)) : (e >> 2), kblk = tr ? (e >> 7) : (e & 3);
     const int r0 = isb ? n0 : m0, rmax = isb ? G.N : G.M;
     const long rs = isb ? G.brs : G.ars, ks = isb ? G.bks : G.aks;
@@ -117,18 +124,18 @@ __global__ __launch_bounds__(GNT, 2) void gemm_nt_f16x3_kernel(GArgs G) {
     u_dst[u] = (isb ? G_NP * G_PL : 0) + kblk * G_KB + row;
   }
 
-  float rg[G_PD][4][8];
+  float rg[G_PD][2 * G_NU][8];
   auto load_stage = [&](int slot, int st) {            // st: stage index within this split
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      load8(rg[slot][u], up[u] + (size_t)st * GKC * (u >= 2 ? G.bks : G.aks), u >= 2 ? G.bks : G.aks, u >= 2 ? BT : AT);
+    for (int u = 0; u < 2 * G_NU; ++u)
+      load8(rg[slot][u], up[u] + (size_t)st * GKC * (u >= G_NU ? G.bks : G.aks), u >= G_NU ? G.bks : G.aks, u >= G_NU ? BT : AT);
   };
   // one staged unit: scale, split into hi / lo, two LDS units
   auto piece = [&](int slot, int u, f32x4* base) {
     float* v = rg[slot][u];
     // rows beyond M / N (clamped re-reads of the last row) are multiplied by zero: they only ever meet output rows /
     // columns that are not stored
-    const float sc = u_ok[u] ? (u >= 2 ? b_scale : a_scale) : 0.f;
+    const float sc = u_ok[u] ? (u >= G_NU ? b_scale : a_scale) : 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] *= sc;
     f32x4 pl[G_NP];
@@ -140,21 +147,23 @@ __global__ __launch_bounds__(GNT, 2) void gemm_nt_f16x3_kernel(GArgs G) {
     base[u_dst[u]] = pl[0];
     base[u_dst[u] + G_PL] = pl[1];
   };
-  auto read_frags = [&](bf16x8 (&av)[2][G_NP], bf16x8 (&bv)[2][G_NP], const f32x4* base, int s2) {
+  auto read_frags = [&](bf16x8 (&av)[2][G_NP], bf16x8 (&bv)[G_HN][G_NP], const f32x4* base, int s2) {
 #pragma unroll
-    for (int p = 0; p < G_NP; ++p)
+    for (int p = 0; p < G_NP; ++p) {
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
+      for (int g = 0; g < 2; ++g)
         av[g][p] = __builtin_bit_cast(bf16x8, base[p * G_PL + (2 * s2 + kb) * G_KB + wm * 64 + g * 32 + l32]);
-        bv[g][p] = __builtin_bit_cast(bf16x8, base[(G_NP + p) * G_PL + (2 * s2 + kb) * G_KB + wn * 64 + g * 32 + l32]);
-      }
+#pragma unroll
+      for (int h = 0; h < G_HN; ++h)
+        bv[h][p] = __builtin_bit_cast(bf16x8, base[(G_NP + p) * G_PL + (2 * s2 + kb) * G_KB + wcol + h * 32 + l32]);
+    }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][G_HN];
 #pragma unroll
   for (int g = 0; g < 2; ++g)
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < G_HN; ++h)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[g][h][r] = 0.f;
 
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(GNT, 2) void gemm_nt_f16x3_kernel(GArgs G) {
 #pragma unroll
     for (int j = 0; j < G_PD; ++j) load_stage(j, min(j, nst - 1));
 #pragma unroll
-    for (int u = 0; u < 4; ++u) piece(0, u, lds);
+    for (int u = 0; u < 2 * G_NU; ++u) piece(0, u, lds);
     __syncthreads();
     // One stage: 6 groups of 4 MFMAs (2 steps of 16 x the 3 plane products); the split of stage st + 1 (4 units) rides
     // on the first four groups, the second step's fragments are read during the first step's second group.  `j`: the
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(GNT, 2) void gemm_nt_f16x3_kernel(GArgs G) {
       const f32x4* base = lds + buf * BUFU;
       f32x4* nxt = lds + (buf ^ 1) * BUFU;           // stage st + 1 (loaded G_PD - 1 stages ago) goes here --
                                                      // after the last stage too (a re-store nobody reads): no branch
-      bf16x8 av0[2][G_NP], bv0[2][G_NP], av1[2][G_NP], bv1[2][G_NP];
+      bf16x8 av0[2][G_NP], bv0[G_HN][G_NP], av1[2][G_NP], bv1[G_HN][G_NP];
       load_stage(j, min(st + G_PD, nst - 1));        // slot j held stage st: split during stage st - 1
       read_frags(av0, bv0, base, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -189,14 +198,14 @@ __global__ __launch_bounds__(GNT, 2) void gemm_nt_f16x3_kernel(GArgs G) {
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll
-              for (int h = 0; h < 2; ++h)
+              for (int h = 0; h < G_HN; ++h)
                 if constexpr ((VG_GEMM_ABL & 8) == 0)
                 acc[g][h] = s2 == 0 ? mfma_split16<true>(av0[g][pa], bv0[h][sum - pa], acc[g][h])
                                     : mfma_split16<true>(av1[g][pa], bv1[h][sum - pa], acc[g][h]);
             if constexpr ((VG_GEMM_ABL & 16) != 0) {       // timing experiment: the split rides on the LAST four groups
-              if (grp >= 2) piece((j + 1) % G_PD, grp - 2, nxt);
+              if (grp >= 6 - 2 * G_NU) piece((j + 1) % G_PD, grp - (6 - 2 * G_NU), nxt);
             } else
-            if (grp < 4) piece((j + 1) % G_PD, grp, nxt);
+            if (grp < 2 * G_NU) piece((j + 1) % G_PD, grp, nxt);
             if (grp == 1) read_frags(av1, bv1, base, 1);
             __builtin_amdgcn_sched_barrier(0);
             ++grp;
@@ -218,8 +227,8 @@ __global__ __launch_bounds__(GNT, 2) void gemm_nt_f16x3_kernel(GArgs G) {
   const float ua = f16_unscale_of(*G.a_amax), ub = f16_unscale_of(*G.b_amax);
   float* out = G.C + (G.ksplit > 1 ? (size_t)split * G.M * G.N : 0);
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int n = n0 + wn * 64 + h * 32 + l32;
+  for (int h = 0; h < G_HN; ++h) {
+    const int n = n0 + wcol + h * 32 + l32;
     const float bvv = (G.bias && split == 0 && n < G.N) ? G.bias[n] : 0.f;
 #pragma unroll
     for (int g = 0; g < 2; ++g)
@@ -229,6 +238,25 @@ __global__ __launch_bounds__(GNT, 2) void gemm_nt_f16x3_kernel(GArgs G) {
         if (m < G.M && n < G.N) out[(size_t)m * G.N + n] = acc[g][h][r16] * ua * ub + bvv;
       }
   }
+}
+
+// C[i] = sum over `splits` slabs of n floats, slab order (fixed: reproducible); n % 4 == 0.  16-byte loads, eight slabs
+// in flight per thread (the shared dword-per-lane reduce of conv_wgrad.hip took 10 us for these 17 MB: launch-bound).
+__global__ __launch_bounds__(256) void gemm_slab_sum_kernel(const f32x4* __restrict__ slabs, f32x4* __restrict__ C, int n4,
+                                                           int splits) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 8 <= splits; k += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = slabs[(size_t)(k + j) * n4 + i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  for (; k < splits; ++k) s += slabs[(size_t)k * n4 + i];
+  C[i] = s;
 }
 
 #ifndef G_TARGET_WGS
@@ -284,6 +312,15 @@ extern "C" int vg_gemm_nt_f16x3(const float* A, const float* B, const float* bia
   else if (bt) hipLaunchKernelGGL((gemm_nt_f16x3_kernel<false, true>), g, b, 0, st, G);
   else hipLaunchKernelGGL((gemm_nt_f16x3_kernel<false, false>), g, b, 0, st, G);
   VG_CHECK_LAUNCH();
-  if (ks > 1) return vg_internal_wgrad_reduce((const float*)workspace, C, M * N, ks, st);   // fixed-order sum of the slabs
+  if (ks > 1) {                                      // fixed-order sum of the slabs
+    const long n = (long)M * N;
+    if (n % 4 == 0 && ((uintptr_t)C & 15) == 0 && ((uintptr_t)workspace & 15) == 0) {
+      hipLaunchKernelGGL(gemm_slab_sum_kernel, dim3((unsigned)cdiv(n / 4, 256)), dim3(256), 0, st, (const f32x4*)workspace,
+                         (f32x4*)C, (int)(n / 4), ks);
+      VG_CHECK_LAUNCH();
+      return 0;
+    }
+    return vg_internal_wgrad_reduce((const float*)workspace, C, M * N, ks, st);
+  }
   return 0;
 }
