@@ -22,6 +22,8 @@
 // where it is not -- G_PD stages ahead in registers, splits them into planes and writes two 16-byte LDS units each
 // ([plane][k-block][row], k-blocks padded by two units so that the 4 lanes that share a row do not share banks);
 // stages are double-buffered in LDS, ONE barrier per stage.  Plain loads only: hipcc counts vmcnt itself.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "vaegan_hip.h"
 
@@ -263,10 +265,14 @@ __global__ __launch_bounds__(256) void gemm_slab_sum_kernel(const f32x4* __restr
 #define G_TARGET_WGS 256
 #endif
 // K split: as many splits as keep >= 8 stages each and bring the grid to about G_TARGET_WGS workgroups
+int gemm_target_wgs() {      // (VG_GEMM_TARGET_WGS: timing experiments)
+  static const int t = [] { const char* e = getenv("VG_GEMM_TARGET_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : G_TARGET_WGS; }();
+  return t;
+}
 int gemm_ksplit(int M, int N, int K) {
   const long tiles = (long)cdiv(M, GTM) * cdiv(N, GTN);
   int ks = 1;
-  while (tiles * ks * 2 <= G_TARGET_WGS && K % (GKC * ks * 2) == 0 && K / (ks * 2) >= 8 * GKC) ks *= 2;
+  while (tiles * ks * 2 <= gemm_target_wgs() && K % (GKC * ks * 2) == 0 && K / (ks * 2) >= 8 * GKC) ks *= 2;
   return ks;
 }
 
