@@ -15,7 +15,7 @@
 // with three bf16 planes -- 6 MFMAs per multiply, matrix-bound, level with the vendor library -- and removed it; at 3
 // MFMAs the weight stream is the bound.)
 //
-// One workgroup = 4 wavefronts (2 x 2 of 64 x 64: 8 fragment reads per 12 MFMAs) owns a 128 x 128 output tile and a
+// One workgroup = 8 wavefronts (2 x 4 of 64 x 32; G_W8 = 0: 4 of 64 x 64) owns a 128 x 128 output tile and a
 // slice of the reduction (K split over workgroups; partial tiles go to slabs summed in a fixed order: no atomics).  A
 // stage = 32 reduction indices: a thread stages two 8-index units of A and two of B -- two 16-byte loads each where the
 // reduction index is contiguous, eight 4-byte loads (a row apart; consecutive lanes = consecutive rows, coalesced)
@@ -76,10 +76,13 @@ __device__ __forceinline__ void load8(float* r, const float* p, long ks, bool st
 }
 
 // AT / BT: the operand's ROW index is the contiguous one (reduction index strided)
-template <bool AT, bool BT>
-__global__ __launch_bounds__(GNT, 2) void gemm_nt_f16x3_kernel(GArgs G) {
+// R3: three LDS buffers instead of two -- a stage writes the stage after next, so the NEXT stage's first fragments are
+// read under this stage's last MFMAs instead of behind the barrier (the convolution ring's scheme).  100 KB: one
+// workgroup per CU, for the grids that have no more than that anyway.
+template <bool AT, bool BT, bool R3>
+__global__ __launch_bounds__(GNT, R3 ? 1 : 2) void gemm_nt_f16x3_kernel(GArgs G) {
   constexpr int BUFU = G_NP * 2 * G_PL;
-  __shared__ f32x4 lds[2 * BUFU];                      // [buffer][A planes | B planes][k-block][row]
+  __shared__ f32x4 lds[(R3 ? 3 : 2) * BUFU];           // [buffer][A planes | B planes][k-block][row]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kb = lane >> 5, l32 = lane & 31;
@@ -169,6 +172,58 @@ __global__ __launch_bounds__(GNT, 2) void gemm_nt_f16x3_kernel(GArgs G) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[g][h][r] = 0.f;
 
+  if constexpr (R3) {
+   if (nst > 0) {
+    // slots 0, 1, 2 <- stages 0, 1, 2; stages 0 and 1 split into buffers 0 and 1; slot 0 <- stage 3
+#pragma unroll
+    for (int j = 0; j < G_PD; ++j) load_stage(j, min(j, nst - 1));
+#pragma unroll
+    for (int u = 0; u < 2 * G_NU; ++u) piece(0, u, lds);
+#pragma unroll
+    for (int u = 0; u < 2 * G_NU; ++u) piece(1, u, lds + BUFU);
+    load_stage(0, min(3, nst - 1));
+    __syncthreads();
+    bf16x8 xa[2][G_NP], xb[G_HN][G_NP], ya[2][G_NP], yb[G_HN][G_NP];    // fragments of step 0 / step 1 of a stage
+    read_frags(xa, xb, lds, 0);
+    // stage st, j = st % 3 (compile-time): buffer j is read, buffer (j + 1) % 3 holds stage st + 1 (its step-0 fragments
+    // are read under the last MFMAs), stage st + 2 (slot (j + 2) % 3, loaded two stages ago) is split into buffer
+    // (j + 2) % 3 -- last read during stage st - 1 --, stage st + 4 is loaded into slot (j + 1) % 3
+    auto stage3 = [&](int st, int j) {
+      const f32x4* base = lds + j * BUFU;
+      const f32x4* nb = lds + ((j + 1) % 3) * BUFU;
+      f32x4* wr = lds + ((j + 2) % 3) * BUFU;
+      load_stage((j + 1) % G_PD, min(st + 4, nst - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      int grp = 0;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int sum = G_NP - 1; sum >= 0; --sum)
+#pragma unroll
+          for (int pa = sum; pa >= 0; --pa) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+              for (int h = 0; h < G_HN; ++h)
+                acc[g][h] = s2 == 0 ? mfma_split16<true>(xa[g][pa], xb[h][sum - pa], acc[g][h])
+                                    : mfma_split16<true>(ya[g][pa], yb[h][sum - pa], acc[g][h]);
+            if (grp == 0) read_frags(ya, yb, base, 1);
+            if (grp < 2 * G_NU) piece((j + 2) % G_PD, grp, wr);
+            if (grp == 3) read_frags(xa, xb, nb, 0);       // (after the last step-0 MFMA has been issued)
+            __builtin_amdgcn_sched_barrier(0);
+            ++grp;
+          }
+      __syncthreads();
+    };
+    int st = 0;
+    for (; st + G_PD <= nst; st += G_PD) {
+#pragma unroll
+      for (int j = 0; j < G_PD; ++j) stage3(st + j, j);
+    }
+    if (st < nst) stage3(st, 0);
+    if (st + 1 < nst) stage3(st + 1, 1);
+   }
+  } else
   if (nst > 0) {
     // stages past the end re-load the last one (never consumed): every register slot always holds valid data
 #pragma unroll
@@ -313,10 +368,21 @@ extern "C" int vg_gemm_nt_f16x3(const float* A, const float* B, const float* bia
   if (grid > 0x7fffffffL) return VG_ERR_BAD_ARG;
   const bool at = a_k_stride != 1, bt = b_k_stride != 1;
   const dim3 g((unsigned)grid), b(GNT);
-  if (at && bt) hipLaunchKernelGGL((gemm_nt_f16x3_kernel<true, true>), g, b, 0, st, G);
-  else if (at) hipLaunchKernelGGL((gemm_nt_f16x3_kernel<true, false>), g, b, 0, st, G);
-  else if (bt) hipLaunchKernelGGL((gemm_nt_f16x3_kernel<false, true>), g, b, 0, st, G);
-  else hipLaunchKernelGGL((gemm_nt_f16x3_kernel<false, false>), g, b, 0, st, G);
+  // three LDS buffers: measured, not used (the whole benchmark 13.78 ms with it everywhere, 13.65-13.69 where the grid gives
+  // a CU one workgroup anyway, 13.64 without: profiles/r04_logs/r4_gemm_r3.log -- the wavefronts do not wait for the
+  // fragment reads behind the barrier).  VG_GEMM_R3 = 1 / 2: always / on grids <= 256 -- timing experiments.
+  static const int r3_mode = [] { const char* e = getenv("VG_GEMM_R3"); return e ? atoi(e) : 0; }();
+  const bool r3 = r3_mode == 1 || (r3_mode == 2 && grid <= 256);
+#define VG_GEMM_LAUNCH(AT_, BT_)                                                                              \
+  do {                                                                                                        \
+    if (r3) hipLaunchKernelGGL((gemm_nt_f16x3_kernel<AT_, BT_, true>), g, b, 0, st, G);                       \
+    else hipLaunchKernelGGL((gemm_nt_f16x3_kernel<AT_, BT_, false>), g, b, 0, st, G);                         \
+  } while (0)
+  if (at && bt) VG_GEMM_LAUNCH(true, true);
+  else if (at) VG_GEMM_LAUNCH(true, false);
+  else if (bt) VG_GEMM_LAUNCH(false, true);
+  else VG_GEMM_LAUNCH(false, false);
+#undef VG_GEMM_LAUNCH
   VG_CHECK_LAUNCH();
   if (ks > 1) {                                      // fixed-order sum of the slabs
     const long n = (long)M * N;
