@@ -91,6 +91,13 @@ def test_pure_host_entry_points(lib_path):
     assert lib.vg_conv5x5_packed_bf16split_bytes(256, 128, 3 | 0x100) == 0                     # fp16 planes: two of them
     assert lib.vg_conv5x5_wgrad_bf16split_workspace_bytes(128, 128, 32, 32, 256, 2, 2 | 0x100) > 0
     assert lib.vg_absmax(None, 16, None, None) == -1
+    # Linear GEMM: the K split (and with it the slab workspace) is decided on the host -- 128 x 128 tiles, as many splits
+    # as bring the grid to about 256 workgroups while every split keeps >= 8 stages of 32
+    assert lib.vg_gemm_nt_f16x3_workspace_bytes(128, 2048, 16384) == 16 * 128 * 2048 * 4        # 16 tiles x 16 splits
+    assert lib.vg_gemm_nt_f16x3_workspace_bytes(128, 16384, 2048) == 2 * 128 * 16384 * 4        # data gradient: 128 tiles x 2
+    assert lib.vg_gemm_nt_f16x3_workspace_bytes(2048, 16384, 128) == 0                          # weight gradient: 2048 tiles
+    assert lib.vg_gemm_nt_f16x3_workspace_bytes(128, 2048, 100) == 0                            # K % 32: not taken
+    assert lib.vg_gemm_nt_f16x3(None, None, None, None, 128, 2048, 16384, 16384, 1, 16384, 1, None, None, None, 0, None) == -1
 
 
 def test_ops_refuse_cpu_tensors():

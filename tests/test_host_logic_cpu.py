@@ -341,3 +341,27 @@ def test_fp16x3_is_the_default_arithmetic_and_planes_codes_match_the_header():
             assert ops._planes() == planes and ops._thin_planes() == (3 if mode == "fp16x3" else planes)
     finally:
         ops.CONV_ARITH = prev
+
+
+def test_linear_layers_dispatch_and_the_adam_tensor_struct_match_the_header():
+    """Which Linear GEMMs leave the vendor library (ops.linear_split_ok), and that the ctypes mirror of VgAdamTensor has the
+    header's fields in the header's order (the struct grew by `amax` in ABI 5)."""
+    import os, re
+    from disentangle_mlp_amd import ops, optim
+    prev = ops.CONV_ARITH, ops.LINEAR_SPLIT
+    try:
+        ops.CONV_ARITH, ops.LINEAR_SPLIT = "fp16x3", True
+        assert ops.linear_split_ok(16384, 16384 * 2048) and ops.linear_split_ok(128, 128 * 16384)
+        assert not ops.linear_split_ok(2048, 2048 * 128)          # the 2048 -> 128 heads: below 2^20 weights
+        assert not ops.linear_split_ok(100, 16384 * 2048)         # reduction not a multiple of 32 (odd batches' weight gradient)
+        ops.CONV_ARITH = "bf16x6"
+        assert not ops.linear_split_ok(16384, 16384 * 2048)       # opt-in arithmetics: vendor GEMMs
+        ops.CONV_ARITH, ops.LINEAR_SPLIT = "fp16x3", False
+        assert not ops.linear_split_ok(16384, 16384 * 2048)
+    finally:
+        ops.CONV_ARITH, ops.LINEAR_SPLIT = prev
+    hdr = open(os.path.join(os.path.dirname(ops.__file__), "..", "include", "vaegan_hip.h")).read()
+    body = re.search(r"typedef struct \{([^}]*)\} VgAdamTensor;", hdr).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = [re.findall(r"(\w+)\s*;", line)[0] for line in body.split("\n") if ";" in line]
+    assert fields == [f[0] for f in optim._AdamTensor._fields_] == ["p", "g", "m", "v", "n", "amax"]
