@@ -58,7 +58,7 @@ SIGNATURES = {
     "vg_conv5x5_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _I, _P]),
     "vg_channel_sum": (_I, [_P, _P, _I, _I, _I, _P, _Z, _P]),
     "vg_bn_workspace_bytes": (_Z, [_I]),
-    "vg_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P, _Z, _P]),
+    "vg_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P, _P, _Z, _P]),
     "vg_bn_act_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
     "vg_bn_finalize_stats": (_I, [_P, _I, _I, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _Z, _P]),
     "vg_bn_stats": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _Z, _P]),

@@ -196,7 +196,11 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
   unsigned am = 0;
   auto one = [&](float xv, float gv) -> float {
     const float pre = fmaf(xv, sc, sh);
-    if (!BWD) return act_fwd(pre, act);
+    if (!BWD) {
+      const float r = act_fwd(pre, act);
+      am = max(am, abs_bits(r));
+      return r;
+    }
     const float g = act_grad(pre, gv, act);
     const float r = sc * (g - c1 - ((xv - mu) * is) * c2);
     am = max(am, abs_bits(r));
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
       out[off] = one(x[off], BWD ? gy[off] : 0.f);
     }
   }
-  if (BWD && out_amax) block_amax_atomic<NT>(am, out_amax);      // wave-uniform condition
+  if (out_amax) block_amax_atomic<NT>(am, out_amax);      // wave-uniform condition
 }
 
 // Backward in ONE pass for channels that fit a workgroup's registers (B * HW <= ONE_NT * 4 * NV elements: the 16 x 16 and
@@ -747,8 +751,8 @@ extern "C" int vg_affine_act(const float* x, const float* scale, const float* sh
 
 extern "C" int vg_bn_act_fwd(const float* x, const float* gamma, const float* beta, float* y, float* running_mean,
                              float* running_var, float* save_mean, float* save_invstd, int B, int C, int HW,
-                             float eps, float momentum, int act, void* workspace, size_t workspace_bytes,
-                             void* stream) {
+                             float eps, float momentum, int act, float* y_amax, void* workspace,
+                             size_t workspace_bytes, void* stream) {
   if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || B <= 0 || C <= 0 || HW <= 0)
     return VG_ERR_BAD_ARG;
   if (act < VG_ACT_NONE || act > VG_ACT_LRELU) return VG_ERR_BAD_ARG;
@@ -768,7 +772,8 @@ extern "C" int vg_bn_act_fwd(const float* x, const float* gamma, const float* be
   const Slicing a = make_apply_slicing(B, C, HW);
   hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(C, a.ns), dim3(NT), 0, st, x, (const float*)nullptr,
                      (const double*)part, s.ns, gamma, beta, save_mean, save_invstd, running_mean, running_var,
-                     (float*)nullptr, (float*)nullptr, y, B, C, HW, a.per, eps, momentum, act, (unsigned*)nullptr);
+                     (float*)nullptr, (float*)nullptr, y, B, C, HW, a.per, eps, momentum, act,
+                     reinterpret_cast<unsigned*>(y_amax));
   VG_CHECK_LAUNCH();
   return 0;
 }

@@ -492,8 +492,8 @@ def linear(x, w, bias, bias_grad=BIAS_GRAD_COMPUTE):
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, act=ops.ACT_NONE, stats=None):
-    return BNActFn.apply(x, gamma, beta, running_mean, running_var, eps, momentum, act,
-                         stats if stats is not None and stats.numel() else None)
+    return ops.adopt_amax(BNActFn.apply(x, gamma, beta, running_mean, running_var, eps, momentum, act,
+                                        stats if stats is not None and stats.numel() else None))
 
 
 def conv_with_stats(x, w, bias, stride, transposed=False, bias_grad=BIAS_GRAD_COMPUTE):

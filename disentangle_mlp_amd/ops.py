@@ -173,10 +173,27 @@ class amax_capture_scope:
         return False
 
 
+_last_amax = None      # (data_ptr, shape, slot) of the latest plain set_amax: see adopt_amax
+
+
 def set_amax(t, slot, in_affine=None):
     """Remember ``slot`` as the bound of ``t`` (as read through ``in_affine``); returns ``slot``."""
+    global _last_amax
     t._vg_amax = (t._version, None if in_affine is None else id(in_affine[0]), slot)
+    if in_affine is None:
+        _last_amax = (t.data_ptr(), tuple(t.shape), slot)
     return slot
+
+
+def adopt_amax(out):
+    """``out`` is what a torch.autograd.Function just returned: autograd hands back a NEW tensor object for the tensor its
+    forward produced, without the Python attribute the producing kernel's wrapper attached.  If ``out`` is that tensor
+    (same memory, same shape, set just now), it inherits the bound."""
+    global _last_amax
+    la, _last_amax = _last_amax, None
+    if la is not None and la[0] == out.data_ptr() and la[1] == tuple(out.shape) and not hasattr(out, "_vg_amax"):
+        out._vg_amax = (out._version, None, la[2])
+    return out
 
 
 def keep_amax(src, view):
@@ -689,9 +706,12 @@ def bn_act_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, act):
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     invstd = torch.empty(C, dtype=torch.float32, device=x.device)
     ws = workspace(lib.vg_bn_workspace_bytes(C), x.device)
+    slot = _amax_slot(x.device) if (_f16() and HW > 1) else None      # max |y| on the way out (as affine_act)
     check(lib.vg_bn_act_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(running_mean),
-                            _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), B, C, HW, eps, momentum, act,
+                            _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), B, C, HW, eps, momentum, act, _ptr(slot),
                             ws.data_ptr(), ws.numel(), _stream()), "vg_bn_act_fwd")
+    if slot is not None:
+        set_amax(y, slot)
     return y, mean, invstd
 
 

@@ -264,11 +264,13 @@ int vg_channel_sum(const float* g, float* out, int B, int C, int HW,
  * nn.BatchNorm2d/1d in train mode: model.py:451-458,462,468,492,496-505,390-400
  * (the reference never calls .eval()).  save_mean / save_invstd ([C]) are kept
  * for the backward.  running_mean / running_var may be NULL.
+ * y_amax (may be NULL; ignored for HW == 1): max |y| is added to y_amax[0] (atomic maximum, DEVICE memory, zeroed by the
+ * caller) -- the bound the fp16-plane consumers of y (a convolution, vg_gemm_nt_f16x3) scale it by.
  * workspace >= vg_bn_workspace_bytes(C). */
 size_t vg_bn_workspace_bytes(int C);
 int vg_bn_act_fwd(const float* x, const float* gamma, const float* beta, float* y,
                   float* running_mean, float* running_var, float* save_mean, float* save_invstd,
-                  int B, int C, int HW, float eps, float momentum, int act,
+                  int B, int C, int HW, float eps, float momentum, int act, float* y_amax,
                   void* workspace, size_t workspace_bytes, void* stream);
 /* gx, dgamma, dbeta from gy, the saved x and statistics (the activation mask is
  * recomputed from x, bit-identically to the forward). gx must not alias gy. */
