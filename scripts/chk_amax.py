@@ -1,3 +1,6 @@
+"""Which bounds of max |tensor| (ops.amax_of) a Discriminator forward + backward finds attached by a producer ("cached") and
+which it has to measure with a pass of its own.  (The conv-chain entries with a BatchNorm-on-load print MEASURED although their
+bound travels in the in_affine tuple: the spy looks at the tensor attribute only.)"""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
