@@ -64,7 +64,7 @@ SIGNATURES = {
     "vg_bn_stats": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _Z, _P]),
     "vg_affine_act": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "vg_bias_act_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    "vg_act_bwd": (_I, [_P, _P, _P, _Z, _I, _P]),
+    "vg_act_bwd": (_I, [_P, _P, _P, _Z, _I, _P, _P]),
     "vg_reparam_kl_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "vg_reparam_kl_bwd": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _P]),
     "vg_scale_by_scalar": (_I, [_P, _P, _P, _Z, _P]),

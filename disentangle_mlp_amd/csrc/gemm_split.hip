@@ -297,25 +297,6 @@ __global__ __launch_bounds__(GNT, R3 ? 1 : 2) void gemm_nt_f16x3_kernel(GArgs G)
   }
 }
 
-// C[i] = sum over `splits` slabs of n floats, slab order (fixed: reproducible); n % 4 == 0.  16-byte loads, eight slabs
-// in flight per thread (the shared dword-per-lane reduce of conv_wgrad.hip took 10 us for these 17 MB: launch-bound).
-__global__ __launch_bounds__(256) void gemm_slab_sum_kernel(const f32x4* __restrict__ slabs, f32x4* __restrict__ C, int n4,
-                                                           int splits) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  int k = 0;
-  for (; k + 8 <= splits; k += 8) {
-    f32x4 v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = slabs[(size_t)(k + j) * n4 + i];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s += v[j];
-  }
-  for (; k < splits; ++k) s += slabs[(size_t)k * n4 + i];
-  C[i] = s;
-}
-
 #ifndef G_TARGET_WGS
 #define G_TARGET_WGS 256
 #endif
@@ -384,15 +365,6 @@ extern "C" int vg_gemm_nt_f16x3(const float* A, const float* B, const float* bia
   else VG_GEMM_LAUNCH(false, false);
 #undef VG_GEMM_LAUNCH
   VG_CHECK_LAUNCH();
-  if (ks > 1) {                                      // fixed-order sum of the slabs
-    const long n = (long)M * N;
-    if (n % 4 == 0 && ((uintptr_t)C & 15) == 0 && ((uintptr_t)workspace & 15) == 0) {
-      hipLaunchKernelGGL(gemm_slab_sum_kernel, dim3((unsigned)cdiv(n / 4, 256)), dim3(256), 0, st, (const f32x4*)workspace,
-                         (f32x4*)C, (int)(n / 4), ks);
-      VG_CHECK_LAUNCH();
-      return 0;
-    }
-    return vg_internal_wgrad_reduce((const float*)workspace, C, M * N, ks, st);
-  }
+  if (ks > 1) return vg_internal_wgrad_reduce((const float*)workspace, C, M * N, ks, st);   // fixed-order sum of the slabs
   return 0;
 }

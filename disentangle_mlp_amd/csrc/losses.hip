@@ -49,9 +49,11 @@ __global__ __launch_bounds__(NT) void bias_act_fwd_kernel(const float* __restric
 }
 
 __global__ __launch_bounds__(NT) void act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
-                                                     float* __restrict__ gx, size_t n, int kind) {
+                                                     float* __restrict__ gx, size_t n, int kind,
+                                                     unsigned* __restrict__ gx_amax) {
   const size_t stride = (size_t)gridDim.x * NT;
   const size_t n4 = n >> 2;
+  unsigned am = 0;      // max |gx| for an fp16-plane consumer (the Linear data / weight-gradient GEMMs): vg_act_bwd
   for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += stride) {
     const float4 g = reinterpret_cast<const float4*>(gy)[i];
     const float4 v = reinterpret_cast<const float4*>(y)[i];
@@ -60,10 +62,15 @@ __global__ __launch_bounds__(NT) void act_bwd_kernel(const float* __restrict__ g
     o.y = ew_bwd(g.y, v.y, kind);
     o.z = ew_bwd(g.z, v.z, kind);
     o.w = ew_bwd(g.w, v.w, kind);
+    am = max(max(am, abs_bits(o.x)), max(max(abs_bits(o.y), abs_bits(o.z)), abs_bits(o.w)));
     reinterpret_cast<float4*>(gx)[i] = o;
   }
-  for (size_t i = (n4 << 2) + (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride)
-    gx[i] = ew_bwd(gy[i], y[i], kind);
+  for (size_t i = (n4 << 2) + (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) {
+    const float o = ew_bwd(gy[i], y[i], kind);
+    am = max(am, abs_bits(o));
+    gx[i] = o;
+  }
+  if (gx_amax) block_amax_atomic<NT>(am, gx_amax);
 }
 
 // One workgroup of 1024 threads (16 wavefronts); a wavefront owns a row at a time,
@@ -287,9 +294,11 @@ extern "C" int vg_bias_act_fwd(const float* x, const float* bias, float* y, int 
   return 0;
 }
 
-extern "C" int vg_act_bwd(const float* gy, const float* y, float* gx, size_t n, int act_kind, void* stream) {
+extern "C" int vg_act_bwd(const float* gy, const float* y, float* gx, size_t n, int act_kind, float* gx_amax,
+                          void* stream) {
   if (!gy || !y || !gx || n == 0 || act_kind < 0 || act_kind > 2) return VG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(flat_grid(n)), dim3(NT), 0, (hipStream_t)stream, gy, y, gx, n, act_kind);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(flat_grid(n)), dim3(NT), 0, (hipStream_t)stream, gy, y, gx, n, act_kind,
+                     reinterpret_cast<unsigned*>(gx_amax));
   VG_CHECK_LAUNCH();
   return 0;
 }

@@ -806,7 +806,10 @@ def act_bwd(gy, y, kind):
     lib = _lib.load()
     _req(gy, "gy"), _req(y, "y")
     gx = torch.empty_like(y)
-    check(lib.vg_act_bwd(gy.data_ptr(), y.data_ptr(), gx.data_ptr(), y.numel(), kind, _stream()), "vg_act_bwd")
+    slot = _amax_slot(y.device) if (_f16() and LINEAR_SPLIT and y.dim() == 2) else None      # feeds a Linear layer's backward GEMMs
+    check(lib.vg_act_bwd(gy.data_ptr(), y.data_ptr(), gx.data_ptr(), y.numel(), kind, _ptr(slot), _stream()), "vg_act_bwd")
+    if slot is not None:
+        set_amax(gx, slot)
     return gx
 
 

@@ -308,7 +308,9 @@ int vg_affine_act(const float* x, const float* scale, const float* shift, float*
  * (model.py:509,565), both with an optional per-channel bias add fused in:
  * y = act(x + bias[c]) for x [B,C,HW]; bias may be NULL. */
 int vg_bias_act_fwd(const float* x, const float* bias, float* y, int B, int C, int HW, int act_kind, void* stream);
-int vg_act_bwd(const float* gy, const float* y, float* gx, size_t n, int act_kind, void* stream);
+/* gx_amax (may be NULL): max |gx| is added to gx_amax[0] (atomic maximum; DEVICE memory, zeroed by the caller) -- the bound an
+ * fp16-plane consumer of gx (the Linear layers' backward GEMMs) scales it by */
+int vg_act_bwd(const float* gy, const float* y, float* gx, size_t n, int act_kind, float* gx_amax, void* stream);
 #define VG_EW_LRELU 0
 #define VG_EW_TANH 1
 #define VG_EW_SIGMOID 2
