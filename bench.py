@@ -248,6 +248,7 @@ def main():
 
     B = args.batch
     arith = ops.CONV_ARITH               # the product default unless VG_CONV_ARITH was exported
+    linear_own = bool(ops.LINEAR_SPLIT and arith == "fp16x3")     # ops.linear_split_ok: the big Linear layers leave the vendor GEMMs
     alone = world == 1 and dist.is_initialized()
     if alone:
         from disentangle_mlp_amd.trainer import FlatGrads
@@ -425,11 +426,16 @@ def main():
             "untimed_preparation_steps": prep_steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32" if arith == "fp32" else
-                     "fp32-equivalent (%s split of fp32 operands on the %s MFMA, fp32 accumulate, every convolution; "
-                     "Linear layers, BatchNorm, losses, Adam in fp32)" % (arith, "f16" if arith == "fp16x3" else "bf16")
+                     "fp32-equivalent (%s split of fp32 operands on the %s MFMA, fp32 accumulate, every convolution%s; "
+                     "%sBatchNorm, losses, Adam in fp32)" % (
+                         arith, "f16" if arith == "fp16x3" else "bf16",
+                         " and the Linear layers with >= 2^20 weights (vg_gemm_nt_f16x3)" if linear_own else "",
+                         "the small Linear layers (vendor GEMMs), " if linear_own else "Linear layers (vendor GEMMs), ")
                      if arith in ("bf16x6", "fp16x3") else
                      arith + " (split-bf16 operands on the bf16 MFMA, fp32 accumulate) + fp32 elsewhere",
             "arithmetic": ARITH_NOTE[arith],
+            "linear_gemm": "own fp16x3 GEMM (csrc/gemm_split.hip) for layers with >= 2^20 weights, vendor fp32 GEMMs for the rest"
+                           if linear_own else "vendor fp32 GEMMs (hipBLASLt / rocBLAS, tuned table)",
             "data": "synthetic",
             "config": {"workload": "new_betavaegan.py beta=25 VAE-GAN iteration (D + decoder + encoder phases, "
                                    "3 Adam steps), CelebA 64x64, per-GPU batch %d" % B,
