@@ -15,7 +15,7 @@ print(f"total {tot / 1e3:.3f} ms per iteration over {len(rows)} kernels")
 fam = {}
 for t, c, a, n in out:
     key = ("ring conv" if "ring_kernel" in n else "wgrad split" if "wgrad_split8" in n else "other split conv" if "bf16split_kernel" in n
-           else "thin (3-channel)" if "thin" in n else "relayout gy" if "relayout" in n else "slab sums" if "reduce" in n
+           else "thin (3-channel)" if "thin" in n else "relayout gy" if "relayout" in n else "slab sums" if ("reduce" in n or "slab_sum" in n)
            else "BatchNorm" if ("bn_" in n or "bn1d" in n or "affine_act" in n or "stats_partial" in n) else "Adam" if "adam" in n
            else "absmax" if "absmax" in n else "pack" if "pack" in n else "vendor GEMM" if ("Cijk" in n or "gemm" in n.lower()) else "other")
     fam[key] = fam.get(key, 0.0) + t
