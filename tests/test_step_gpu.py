@@ -737,4 +737,4 @@ def test_fused_conv_bn_equals_two_pass_batchnorm(T, batch):
             if float(r.norm()) == 0.0 or k in BN_SHADOWED[key]:      # shadowed biases: rounding noise on both sides
                 continue
             e = float((res[True][1][ph][k] - r).norm() / r.norm())
-            assert e <= grad_tol, (ph, k, e)
+            assert e <= grad_tol, (ph, k, e, "flipped units:", flips)
