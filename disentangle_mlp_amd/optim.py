@@ -189,8 +189,10 @@ class HipAdam(optim.Adam):
                                        bc1, bc2_sqrt, stream), "vg_adam_step")
         if bounds is not None:
             for p, bi in self._bound_of.items():
-                if p.grad is not None:
-                    ops.set_weight_bound(p, bounds[bi:bi + 1])
+                slot = bounds[bi:bi + 1]
+                if p.grad is None:      # not stepped: its word was zeroed with the others -- measured again (rare: a frozen layer)
+                    check(lib.vg_absmax(p.data_ptr(), p.numel(), slot.data_ptr(), stream), "vg_absmax")
+                ops.set_weight_bound(p, slot)
         return None
 
     @torch.no_grad()

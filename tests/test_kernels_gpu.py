@@ -1169,6 +1169,9 @@ def test_adam_step_emits_the_bound_of_big_linear_weights(H):
         opt.step()
         b = H.weight_bound(w)
         assert b.data_ptr() == opt._bounds.data_ptr() and float(b) == float(w.detach().abs().max())
+    w.grad, small.grad = None, torch.randn(64, 64, generator=g).cuda()       # a step that does not touch w: the bound stays true
+    opt.step()
+    assert float(H.weight_bound(w)) == float(w.detach().abs().max()) and H.weight_bound(w).data_ptr() == opt._bounds.data_ptr()
     with H.packed_filter_scope():                       # survives scope boundaries (a trainer opens one per iteration)
         assert H.weight_bound(w).data_ptr() == opt._bounds.data_ptr()
     with torch.no_grad():
