@@ -620,21 +620,26 @@ def linear_split_ok(reduction, nweights):
     return LINEAR_SPLIT and _f16() and reduction % 32 == 0 and nweights >= LINEAR_SPLIT_MIN_WEIGHTS
 
 
-_wbound_emitted = {}      # data_ptr -> (version, shape, bound): what the optimizer step that last wrote the weight emitted
+_wbound_emitted = {}      # id(weight) -> (weak reference, version, bound): what the optimizer step that last wrote it emitted
 
 
 def set_weight_bound(w, bound):
     """``bound`` (one-element device tensor) holds max |w| as of now -- HipAdam's step emits it (VgAdamTensor.amax).
-    Valid until the next torch-side in-place write (the version counter) or the next call for this weight."""
-    _wbound_emitted[w.data_ptr()] = (w._version, tuple(w.shape), bound)
+    Valid for THIS tensor object (a weak reference: an address or id re-used by another tensor never matches) until the
+    next torch-side in-place write (the version counter) or the next call for this weight."""
+    import weakref
+    if len(_wbound_emitted) > 256:                     # weights of trainers that no longer exist
+        for k in [k for k, e in _wbound_emitted.items() if e[0]() is None]:
+            del _wbound_emitted[k]
+    _wbound_emitted[id(w)] = (weakref.ref(w), w._version, bound)
 
 
 def weight_bound(w):
     """Bound of max |w| of a Linear weight: the one the optimizer step emitted when it wrote the weight; failing that,
     inside a `packed_filter_scope`, measured once per weight version (the scope's owner invalidates after optimizer
     steps, as for the packed filters), otherwise per call."""
-    ent = _wbound_emitted.get(w.data_ptr())
-    if ent is not None and ent[0] == w._version and ent[1] == tuple(w.shape):
+    ent = _wbound_emitted.get(id(w))
+    if ent is not None and ent[0]() is w and ent[1] == w._version:
         return ent[2]
     if _pack_scope_depth > 0:
         ent = _wbound_cache.get(w.data_ptr())

@@ -365,3 +365,23 @@ def test_linear_layers_dispatch_and_the_adam_tensor_struct_match_the_header():
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = [re.findall(r"(\w+)\s*;", line)[0] for line in body.split("\n") if ";" in line]
     assert fields == [f[0] for f in optim._AdamTensor._fields_] == ["p", "g", "m", "v", "n", "amax"]
+
+
+def test_emitted_weight_bounds_belong_to_one_tensor_object_and_one_version():
+    """ops.set_weight_bound / weight_bound (the bound HipAdam's step emits for a big Linear weight): a hit needs the SAME
+    tensor object at the SAME version -- not merely the same address, shape or id."""
+    import gc
+    import torch
+    from disentangle_mlp_amd import ops
+    w, b = torch.zeros(4, 4), torch.ones(1)
+    ops.set_weight_bound(w, b)
+    assert ops.weight_bound(w) is b
+    key = id(w)
+    w.add_(1.0)                                   # version bump: stale
+    ent = ops._wbound_emitted[key]
+    assert ent[0]() is w and ent[1] != w._version
+    ops.set_weight_bound(w, b)
+    assert ops.weight_bound(w) is b
+    del w
+    gc.collect()
+    assert ops._wbound_emitted[key][0]() is None   # a new tensor that re-uses the id can never match the dead reference
