@@ -37,6 +37,12 @@ constexpr int RNT = 512;          // 8 wavefronts
 #ifndef VG_RING_REGF
 #define VG_RING_REGF 0
 #endif
+// Timing experiment for the K = 32 body planned in DESIGN.md section 4.10: NO cross-body fragment prefetch -- body k reads
+// the fragments of step k itself, right behind its barrier (the filter DMA of body k then refills the slot of step k - 1,
+// one step less of run-ahead: build with -DVG_RING_SLOTS=4 to keep three).
+#ifndef VG_RING_NOPF
+#define VG_RING_NOPF 0
+#endif
 constexpr int ring_slots(bool f16, int slotu, int patchu) {
   if (!f16) return 3;
   int n = VG_RING_SLOTS;
@@ -436,14 +442,16 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
     filt_load();                                     // step 2 stays in registers until body 0
   } else {
 #pragma unroll
-    for (int i = 0; i < NSLOT; ++i) dma_next(i);
+    for (int i = 0; i < NSLOT - (VG_RING_NOPF ? 1 : 0); ++i) dma_next(i);
   }
   stage_load(c_begin * 16);
   stage_store(0);
   wait_vmcnt<0>();
   __syncthreads();
+  if (!VG_RING_NOPF) {
 #pragma unroll
-  for (int j = 0; j < NRD; ++j) read_one(0, j, 0, patch_off(0, 0));
+    for (int j = 0; j < NRD; ++j) read_one(0, j, 0, patch_off(0, 0));
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
 #ifdef VG_RING_STAMP      // diagnostic build (scripts/ring_stamps.py): where a wavefront's cycles go, summed over its steps --
@@ -535,7 +543,15 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
 #ifndef VG_RING_PLACE
 #define VG_RING_PLACE 0
 #endif
+      if (VG_RING_NOPF) {          // this step's own fragments, behind the barrier
+#pragma unroll
+        for (int j = 0; j < NRD; ++j) read_one(cur, j, slot * SLOTU, patch_off(s, pcur));
+        __builtin_amdgcn_sched_barrier(0);
+      }
       auto mem_block = [&]() {
+        if constexpr (VG_RING_NOPF != 0) {
+          if (!(abl & 1)) dma_next(slot == 0 ? NSLOT - 1 : slot - 1, TWO && (s + NSLOT - 1) % NSTEP >= NA);
+        } else
         if constexpr (REGF) {
           if (!(abl & 1)) {
             filt_store(slot == 0 ? 2 : slot - 1);                                  // step k+2 -> slot (k+2) % 3
@@ -566,7 +582,7 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
           if ((i != 0) == (VG_RING_PLACE == 1 && late)) mem_block();
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (i % RS == RS - 1 && i / RS < NRD) {
+        if (!VG_RING_NOPF && i % RS == RS - 1 && i / RS < NRD) {
           if (!(abl & ((i / RS < FC * NP) ? 32 : 16))) read_one(nxt, i / RS, so, bo);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -577,7 +593,7 @@ __device__ __forceinline__ void ring_body(const RArgs& A, f32x4* lds, int bid, i
         }
       }
 #pragma unroll
-      for (int j = NMF / RS; j < NRD; ++j) read_one(nxt, j, so, bo);     // reads the MFMA count left over
+      for (int j = NMF / RS; j < NRD && !VG_RING_NOPF; ++j) read_one(nxt, j, so, bo);     // reads the MFMA count left over
       if constexpr ((abl & 256) != 0) {
         // timing experiment: what a v_mfma_f32_16x16x32_bf16 build would read on top -- (FC + FP) * 2 * 2 operand
         // registers per step instead of (FC + FP) * 3: one more read per fragment row / column (results discarded)
