@@ -369,6 +369,15 @@ __global__ __launch_bounds__(W8NT, 2) void conv5x5_wgrad_split8_kernel(WXArgs A)
           for (int pa = sum; pa >= 0; --pa)
 #pragma unroll
             for (int f = 0; f < FP; ++f) {
+              if constexpr ((VG_WX_ABL & 32) != 0) {
+                // timing experiment: the same FLOPs as two v_mfma_f32_16x16x32 (numerically meaningless here), as
+                // conv_ring.hip's VG_RING_ABL = 128
+                f32x4 c0 = {acc[f][0], acc[f][1], acc[f][2], acc[f][3]}, c1 = {acc[f][4], acc[f][5], acc[f][6], acc[f][7]};
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[t & PD][pa], bv[f][sum - pa], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[t & PD][pa], bv[f][sum - pa], c1, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { acc[f][r] = c0[r]; acc[f][4 + r] = c1[r]; }
+              } else
               if (!(VG_WX_ABL & 8)) acc[f] = mfma_split16<F16>(av[t & PD][pa], bv[f][sum - pa], acc[f]);
               else acc[f][0] += (float)av[t & PD][pa][0] + (float)bv[f][sum - pa][0];
             }

@@ -1,6 +1,6 @@
 """Ablation timings of the split-bf16 weight gradient (wgrad_bf16split.hip): one process per one-off library built by
 experiments/abl_build.sh wx <bits> (1 gy from a cache-resident pixel, 2 x patch loaded once, 4 patch split + LDS store
-once, 8 no MFMAs, 16 patch fragments read once).  Times the whole op (re-layout + kernel + slab sum).
+once, 8 no MFMAs, 16 patch fragments read once, 32 every product as two 16x16x32 MFMAs -- the shape experiment).  Times the whole op (re-layout + kernel + slab sum).
 Usage: abl_wx.py <bits> ..."""
 import sys, os, statistics, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,5 +30,5 @@ out = []
 for (ci, co, h, s) in ((128, 256, 32, 2), (32, 128, 64, 2), (256, 256, 16, 2), (64, 128, 32, 2), (128, 256, 16, 2)):
     x = torch.randn(B, ci, h, h, device="cuda"); gy = torch.randn(B, co, h // s, h // s, device="cuda")
     out.append(f"{ci}->{co}@{h} {timeit(lambda: ops.conv5x5_wgrad(x, gy, s))*1e3:7.1f} us")
-names = {900: "previous kernel (libabl_wx_900.so, built by hand from an older revision)"} if bits == 900 else {1: "gy cached", 2: "x loaded once", 4: "no split/store", 8: "no MFMA", 16: "no B reads"}
+names = {900: "previous kernel (libabl_wx_900.so, built by hand from an older revision)"} if bits == 900 else {1: "gy cached", 2: "x loaded once", 4: "no split/store", 8: "no MFMA", 16: "no B reads", 32: "16x16x32 MFMA shape"}
 print(f"abl {bits:3d} [{', '.join(v for k, v in names.items() if bits & k) or 'full'}]: " + " | ".join(out), flush=True)
